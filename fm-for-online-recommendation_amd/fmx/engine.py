@@ -1,0 +1,141 @@
+"""FMEngine: workspace + launch sequencing for one FlatTable (sort -> forward -> update on the current stream)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .table import FlatTable
+
+
+class Hyper:
+    """Update-rule hyper-parameters (include/fmx.h fmx_hyper_t)."""
+
+    def __init__(self, lr=0.01, eps=1e-8, alpha=0.05, beta=1.0, l1=0.0, l2=0.0):
+        self.c = _lib.Hyper(lr, eps, alpha, beta, l1, l2)
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+def normalize_inputs(Xi, Xv, n_fields, feature_sizes=None):
+    """The reference's input convention (reference fm_adam.py:35-36): nested lists (or arrays), a single sample may
+    be 1-D.  Returns (idx int32 [B,F] numpy, xv float32 [B,F] numpy or None when every value is exactly 1).
+    Out-of-range indices raise IndexError like nn.Embedding does."""
+    idx = np.asarray(Xi, dtype=np.int64).reshape(-1, n_fields)
+    xv = np.asarray(Xv, dtype=np.float32).reshape(-1, n_fields)
+    if idx.shape != xv.shape:
+        raise ValueError(f"Xi {idx.shape} and Xv {xv.shape} disagree")
+    if feature_sizes is not None:
+        sizes = np.asarray(feature_sizes, dtype=np.int64)[None, :]
+        if (idx < 0).any() or (idx >= sizes).any():
+            raise IndexError("index out of range in self")
+    if np.all(xv == 1.0):
+        xv = None
+    return idx.astype(np.int32), xv
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class FMEngine:
+    def __init__(self, table: FlatTable, max_batch=4096):
+        if not torch.cuda.is_available():
+            raise RuntimeError("fmx needs a ROCm GPU: the hot path has no CPU implementation")
+        self.lib = _lib.load()
+        self.table = table
+        self.device = table.device
+        self.max_batch = 0
+        self._alloc(max_batch)
+
+    def _alloc(self, B):
+        B = int(B)
+        t, dev = self.table, self.device
+        Bp = self.lib.fmx_sorted_width(B)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.sorted = torch.empty((t.n_fields, Bp), dtype=torch.int32, device=dev)
+        self.S = torch.empty((B, t.kp), **f32)
+        self.bi = torch.empty((B, t.kp), **f32)
+        self.first = torch.empty((B, t.n_fields), **f32)
+        self.sfirst = torch.empty(B, **f32)
+        self.sbi = torch.empty(B, **f32)
+        self.logit = torch.empty(B, **f32)
+        self.loss_b = torch.empty(B, **f32)
+        self.dz = torch.empty(B, **f32)
+        self.loss_out = torch.zeros(1, **f32)
+        self.error = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.max_batch = B
+
+    def _ensure(self, B):
+        if B > self.max_batch:
+            self._alloc(B)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _fwd_out(self, want_first=True, want_bi=True):
+        o = _lib.FwdOut()
+        o.S, o.sfirst, o.sbi, o.logit = self.S.data_ptr(), self.sfirst.data_ptr(), self.sbi.data_ptr(), self.logit.data_ptr()
+        o.bi = self.bi.data_ptr() if want_bi else None
+        o.first = self.first.data_ptr() if want_first else None
+        o.loss, o.dz, o.error = self.loss_b.data_ptr(), self.dz.data_ptr(), self.error.data_ptr()
+        return o
+
+    # ---- device inputs ----
+    def to_device(self, idx, xv=None, y=None):
+        dev = self.device
+        idx_d = torch.as_tensor(idx, dtype=torch.int32).to(dev).contiguous()
+        xv_d = None if xv is None else torch.as_tensor(xv, dtype=torch.float32).to(dev).contiguous()
+        y_d = None if y is None else torch.as_tensor(np.asarray(y, dtype=np.float32)).reshape(-1).to(dev).contiguous()
+        return idx_d, xv_d, y_d
+
+    # ---- kernels ----
+    def forward(self, hyper, idx_d, xv_d=None, y_d=None, loss=None, inv_b=None, want_first=True, want_bi=True):
+        B = idx_d.shape[0]
+        self._ensure(B)
+        out = self._fwd_out(want_first, want_bi)
+        inv_b = 1.0 / B if inv_b is None else inv_b
+        _lib.check(self.lib.fmx_fm_forward(self.table.c_struct(), hyper.ref(), idx_d.data_ptr(), _ptr(xv_d), _ptr(y_d), B,
+                                           _lib.LOSSES[loss], inv_b, C.byref(out), self._stream()))
+        return B
+
+    def sort(self, idx_d):
+        B = idx_d.shape[0]
+        self._ensure(B)
+        _lib.check(self.lib.fmx_sort_occurrences(self.table.c_struct(), idx_d.data_ptr(), B, self.sorted.data_ptr(),
+                                                 self.error.data_ptr(), self._stream()))
+
+    def update(self, hyper, rule, B, xv_d, dz_first, dz_bi=None, gbi=None, inv_b=None, with_loss=True):
+        inv_b = 1.0 / B if inv_b is None else inv_b
+        _lib.check(self.lib.fmx_fm_update(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], self.sorted.data_ptr(),
+                                          _ptr(xv_d), self.S.data_ptr(), dz_first.data_ptr(), _ptr(dz_bi), _ptr(gbi), B,
+                                          self.loss_b.data_ptr() if with_loss else None, inv_b,
+                                          self.loss_out.data_ptr() if with_loss else None, self._stream()))
+
+    def step(self, hyper, rule, loss, idx_d, xv_d, y_d, inv_b=None):
+        """One pure-FM mini-batch step; the mean loss lands in self.loss_out[0] (no sync here)."""
+        B = idx_d.shape[0]
+        self._ensure(B)
+        out = self._fwd_out(want_first=False, want_bi=False)
+        inv_b = 1.0 / B if inv_b is None else inv_b
+        _lib.check(self.lib.fmx_fm_step(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss],
+                                        idx_d.data_ptr(), _ptr(xv_d), y_d.data_ptr(), B, inv_b, self.sorted.data_ptr(),
+                                        C.byref(out), self.loss_out.data_ptr(), self._stream()))
+
+    def stream(self, hyper, rule, loss, idx_pool, y_pool, n_steps, loss_out=None, timed=False):
+        """The online loop over a resident pool of batches (fmx_fm_stream).  Returns per-kernel ms when timed."""
+        n_pool, B, F = idx_pool.shape
+        assert F == self.table.n_fields and y_pool.shape == (n_pool, B)
+        self._ensure(B)
+        out = self._fwd_out(want_first=False, want_bi=False)
+        ms = (C.c_float * 3)() if timed else None
+        _lib.check(self.lib.fmx_fm_stream(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss],
+                                          idx_pool.data_ptr(), y_pool.data_ptr(), n_pool, B, 1.0 / B, n_steps,
+                                          self.sorted.data_ptr(), C.byref(out), _ptr(loss_out), ms, self._stream()))
+        return None if ms is None else [float(v) for v in ms]
+
+    def check_error_flag(self):
+        if int(self.error.item()) != 0:
+            self.error.zero_()
+            raise IndexError("index out of range in self (flagged by the fmx kernels)")

@@ -1,0 +1,168 @@
+/* fmx.h -- C ABI of libfmx.so: the MI355X (gfx950) kernels behind the FM / DeepFM / NFM online hot path.
+ *
+ * The reference (haan6/fm-for-online-recommendation) has no FFI layer: its hot path is sequences of ATen ops
+ * inside Python classes.  Each entry point below therefore cites the reference *op sequence* it replaces
+ * (paths relative to the reference repository).  The Python classes in
+ * fm-for-online-recommendation_amd/models/ bind these with ctypes (fm-for-online-recommendation_amd/fmx/_lib.py);
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless the comment says "host";
+ *     nothing is allocated, freed or retained by the library;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no implicit
+ *     synchronisation, and is safe to capture into a hipGraph (fmx_fm_stream with timing excepted);
+ *   - return value: 0 on success, a negative fmx_status otherwise; the message for the calling thread is
+ *     available from fmx_last_error_string();
+ *   - the library never throws and keeps no global mutable state besides the thread-local error string.
+ *
+ * Table layout in HBM (one flat buffer for all fields; field f owns rows [field_offsets[f], field_offsets[f+1])):
+ *   FMX_LAYOUT_WEIGHTS  row = [ V[0..kp) | w | pad ]                 row_stride >= kp + 4
+ *   FMX_LAYOUT_FTRL     row = [ zV[0..kp) | nV[0..kp) | zw | nw | pad ]   row_stride >= 2*kp + 4
+ * kp is k rounded up to 4, 8, 16, 32 or 64; the pad components must be zero (they then stay zero under every
+ * rule).  row_stride is in floats and a multiple of 4 (16-byte rows).  In the FTRL layout the weights are never
+ * stored: w = 0 if |z| <= l1 else -(z - sgn(z) l1) / ((beta + sqrt(n)) / alpha + l2)  (McMahan et al. 2013).
+ */
+#ifndef FMX_H
+#define FMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMX_VERSION 100 /* 0.1.0 */
+
+typedef void *fmx_stream_t; /* hipStream_t */
+
+enum fmx_status {
+  FMX_OK = 0,
+  FMX_ERR_ARG = -1,         /* null pointer / negative size / unknown enum */
+  FMX_ERR_SHAPE = -2,       /* sizes inconsistent with each other (kp, row_stride, Bp, bbits ...) */
+  FMX_ERR_ALIGN = -3,       /* a pointer that must be 16-byte aligned is not */
+  FMX_ERR_LAUNCH = -4,      /* hipGetLastError() after a launch, or another HIP runtime error */
+  FMX_ERR_UNSUPPORTED = -5  /* valid request the kernels do not cover (batch too large for the LDS sort, ...) */
+};
+
+enum fmx_layout { FMX_LAYOUT_WEIGHTS = 0, FMX_LAYOUT_FTRL = 1 };
+
+/* per-coordinate update rules (g = gradient summed over every occurrence of the row in the mini-batch) */
+enum fmx_rule {
+  FMX_RULE_SIGNADAM = 0, /* p -= lr * g / (|g| + eps): what a fresh torch.optim.Adam per call reduces to
+                            (reference fm_adam.py:60,68 / :75,82).  FMX_LAYOUT_WEIGHTS */
+  FMX_RULE_SGD = 1,      /* p -= lr * g (stale notebook prototypes only; parity unpinned).  FMX_LAYOUT_WEIGHTS */
+  FMX_RULE_FTRL = 2      /* FTRL-proximal on (z, n) (not in the reference; parity unpinned).  FMX_LAYOUT_FTRL */
+};
+
+/* loss applied to the FM logit z in the fused epilogue of fmx_fm_forward */
+enum fmx_loss {
+  FMX_LOSS_NONE = 0,
+  FMX_LOSS_BCE_LOGITS = 1, /* BCEwl(z, y)            reference fm_adam.py:61,66 */
+  FMX_LOSS_BCE_SIGMOID = 2 /* BCEwl(sigmoid(z), y)   reference fm_adam.py:76,80 (the "double sigmoid") */
+};
+
+typedef struct fmx_table {
+  float *rows;                  /* [n_rows, row_stride] */
+  const int64_t *field_offsets; /* [n_fields + 1] prefix sums of the per-field vocabulary sizes */
+  float *bias;                  /* WEIGHTS: [1] = bias;  FTRL: [2] = (z, n) of the bias */
+  int64_t n_rows;
+  int32_t n_fields;
+  int32_t k;          /* embedding size */
+  int32_t kp;         /* k padded to 4 / 8 / 16 / 32 / 64 */
+  int32_t row_stride; /* floats */
+  int32_t layout;     /* enum fmx_layout */
+  int32_t reserved;
+  int64_t max_field_rows; /* largest per-field vocabulary (host copy; bounds the sort's composite keys) */
+} fmx_table_t;
+
+typedef struct fmx_hyper {
+  float lr, eps;             /* SIGNADAM / SGD */
+  float alpha, beta, l1, l2; /* FTRL */
+} fmx_hyper_t;
+
+/* Outputs of the forward pass.  Any pointer may be null except S when an update follows. */
+typedef struct fmx_fwd_out {
+  float *S;       /* [B, kp]  S_b = sum_f V[row_bf] * x_bf            (kept for the update)        */
+  float *bi;      /* [B, kp]  0.5 * (S*S - sum_f e*e)                  reference second_order()     */
+  float *first;   /* [B, F]   w[row_bf] * x_bf                         reference first_order()      */
+  float *sfirst;  /* [B]      sum_f first                                                             */
+  float *sbi;     /* [B]      sum_d bi                                                                */
+  float *logit;   /* [B]      sfirst + sbi + bias                      reference forward_fm()       */
+  float *loss;    /* [B]      per-sample loss (unscaled), needs y                                     */
+  float *dz;      /* [B]      d(mean loss)/d logit = (...) * inv_b, needs y                           */
+  int32_t *error; /* [1]      set to 1 when an index is outside its field (that row is treated as 0)  */
+} fmx_fwd_out_t;
+
+int fmx_version(void);
+const char *fmx_last_error_string(void);
+
+/* Smallest sort width for a batch: max(64, next power of two >= B); and log2 of it. */
+int fmx_sorted_width(int B);
+int fmx_sorted_bbits(int B);
+
+/* Gather + bi-interaction forward.
+ * Replaces: first_order / second_order / forward_fm (reference deepfm_adam.py:46-77, fm_adam.py:35-53),
+ * i.e. 2 x 39 nn.Embedding gathers, the two 39-term Python sums and the bi-interaction, plus (loss_kind != NONE)
+ * the BCE-with-logits loss and its derivative (fm_adam.py:61,66 / :76,80).
+ *   idx  [B, F] int32, per-field LOCAL indices exactly as the reference passes them (bit-exact; range-checked)
+ *   xv   [B, F] fp32 feature values or null (== 1.0, the Criteo case)
+ *   y    [B] fp32 labels or null (required when loss_kind != FMX_LOSS_NONE)
+ *   inv_b  1 / (global batch size) folded into dz
+ */
+int fmx_fm_forward(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *xv,
+                   const float *y, int32_t B, int32_t loss_kind, float inv_b, const fmx_fwd_out_t *out,
+                   fmx_stream_t stream);
+
+/* Occurrence lists: for every field, the batch's (local index, sample) pairs sorted by index then sample.
+ * Replaces: the duplicate-row summation embedding_dense_backward performs inside loss.backward()
+ * (reference fm_adam.py:67,81) -- sorting is what makes "reduce per unique row, then
+ * update once" deterministic.
+ *   sorted [F, Bp] uint32, entry = (local index << bbits) | sample, padded with 0xFFFFFFFF;
+ *   Bp = fmx_sorted_width(B), bbits = fmx_sorted_bbits(B); requires (max vocabulary - 1) < (0xFFFFFFFF >> bbits).
+ */
+int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t *sorted, int32_t *error,
+                         fmx_stream_t stream);
+
+/* Row-reduced backward + fused per-row update.
+ * Replaces: loss.backward() into 78 dense table gradients + optimizer.step() over all parameters
+ * (reference fm_adam.py:67-68 / :81-82).  For every unique row of the batch:
+ *     G[b,d]  = dz_bi[b] + gbi[b,d]                       (either term may be absent)
+ *     dV[row] = sum_b x (S_b - x V_row) * G[b,:]          dw[row] = sum_b x dz_first[b]
+ * summed in sample order, then ONE application of `rule` per coordinate.  The bias gets sum_b dz_first[b].
+ *   sorted    from fmx_sort_occurrences for the same idx
+ *   S         [B, kp] from fmx_fm_forward
+ *   dz_first  [B] coefficient of the first-order weights and the bias
+ *   dz_bi     [B] or null: scalar coefficient on every bi component (the FM term sum_d bi_d)
+ *   gbi       [B, kp] or null: dL/dbi from a network on top of bi (DeepFM / NFM)
+ *   loss_b    [B] or null with loss_out [1] or null: loss_out = inv_b * sum_b loss_b (deterministic order)
+ */
+int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const uint32_t *sorted,
+                  const float *xv, const float *S, const float *dz_first, const float *dz_bi, const float *gbi,
+                  int32_t B, const float *loss_b, float inv_b, float *loss_out, fmx_stream_t stream);
+
+/* One pure-FM mini-batch step = sort + forward(+loss) + update on one stream.
+ * Replaces: FMAdam.update_embedding / FMAdam.fit (reference fm_adam.py:56-82) and every class's
+ * update_embedding (deepfm_adam.py:91-104 etc.), which all train on forward_fm only.
+ * Workspace (caller-owned): sorted [F, Bp] u32; fwd->S, fwd->loss, fwd->dz must be non-null. */
+int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
+                const int32_t *idx, const float *xv, const float *y, int32_t B, float inv_b, uint32_t *sorted,
+                const fmx_fwd_out_t *fwd, float *loss_out, fmx_stream_t stream);
+
+/* The online loop over a device-resident stream of mini-batches: step s uses batch (s mod n_pool).
+ * Replaces: the driver loops reference main_experiment.py:92-105 (pre-training) and fm_adam.py:97-99
+ * (run_experiment), batched.  idx_pool [n_pool, B, F], y_pool [n_pool, B]; loss_out [n_steps] or null.
+ * kernel_ms (HOST pointer, [3]) or null: when given, every launch is bracketed with HIP events on `stream` and the
+ * summed durations of {sort, forward, update} in milliseconds are returned after a stream synchronise. */
+int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
+                  const int32_t *idx_pool, const float *y_pool, int32_t n_pool, int32_t B, float inv_b,
+                  int32_t n_steps, uint32_t *sorted, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
+                  fmx_stream_t stream);
+
+/* Streaming read of `bytes` (multiple of 16) with 16-byte loads; sink [1] receives a checksum so the loads stay
+ * live.  Used by bench.py to measure the HBM-read ceiling on the same GPU in the same run. */
+int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMX_H */

@@ -1,0 +1,392 @@
+"""Kernel-level parity: libfmx.so through the C ABI (ctypes) vs the numpy oracle on the same seeded inputs.
+Bit-exact for the integer work (sorted occurrence lists), fp32 within the tolerances written at each check."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CRITEO_SIZES = [63, 113, 126, 51, 224, 148, 100, 79, 104, 9, 32, 57, 82, 1457, 555, 176373, 129683, 305, 19, 11887,
+                632, 3, 41738, 5170, 175446, 3170, 27, 11356, 165602, 10, 4641, 2030, 4, 172761, 18, 15, 57903, 86,
+                44549]
+MIXED_SIZES = [3, 9, 1000, 50000, 4, 17, 200, 31, 7, 2, 1]
+HYP = dict(lr=0.01, eps=1e-8, alpha=0.05, beta=1.0, l1=0.001, l2=0.01)
+
+
+@pytest.fixture(scope="module")
+def fmx():
+    import fmx as _fmx
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _fmx
+
+
+def make_problem(sizes, k, B, seed, real_x=False, zipf=False):
+    rng = np.random.default_rng(seed)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    R = int(offs[-1])
+    if zipf:
+        idx = np.stack([np.minimum(rng.zipf(1.3, size=B) - 1, s - 1) for s in sizes], axis=1).astype(np.int32)
+    else:
+        idx = np.stack([rng.integers(0, s, size=B) for s in sizes], axis=1).astype(np.int32)
+    x = rng.uniform(-1, 1, size=(B, len(sizes))).astype(np.float32) if real_x else None
+    y = (rng.uniform(size=B) < 0.3).astype(np.float32)
+    V = (rng.normal(size=(R, k)) * 0.3).astype(np.float32)
+    w = (rng.normal(size=R) * 0.3).astype(np.float32)
+    bias = np.float32(0.37)
+    return dict(offs=offs, R=R, idx=idx, x=x, y=y, V=V, w=w, bias=bias, rows=idx.astype(np.int64) + offs[:-1][None, :])
+
+
+def weights_table(fmx, sizes, k, pr, stride=None):
+    t = fmx.FlatTable(sizes, k, layout="weights", row_stride=stride)
+    t.rows[:, :k] = torch.from_numpy(pr["V"]).cuda()
+    t.rows[:, t.kp] = torch.from_numpy(pr["w"]).cuda()
+    t.bias[0] = float(pr["bias"])
+    return t
+
+
+def ftrl_state(pr, hyp):
+    h = dict(alpha=hyp["alpha"], beta=hyp["beta"], l1=hyp["l1"], l2=hyp["l2"])
+    rng = np.random.default_rng(5)
+    st = dict(zV=orc.ftrl_z_for_weight(pr["V"], **h), nV=(rng.uniform(size=pr["V"].shape) * 0.5).astype(np.float32),
+              zw=orc.ftrl_z_for_weight(pr["w"], **h), nw=(rng.uniform(size=pr["w"].shape) * 0.5).astype(np.float32),
+              zb=np.float32(-0.4), nb=np.float32(0.2))
+    # a band of coordinates inside the L1 dead zone
+    st["zV"][::7] *= 1e-4
+    return st
+
+
+def ftrl_table(fmx, sizes, k, st, stride=None):
+    t = fmx.FlatTable(sizes, k, layout="ftrl", row_stride=stride)
+    t.load_ftrl_state(st["zV"], st["nV"], st["zw"], st["nw"])
+    t.bias[0], t.bias[1] = float(st["zb"]), float(st["nb"])
+    return t
+
+
+def close(a, b, rtol, floor, what):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, what
+    err = np.abs(a - b)
+    tol = rtol * np.abs(b) + floor
+    assert (err <= tol).all(), f"{what}: max err {err.max():.3e} (tol there {tol.flat[err.argmax()]:.3e}), n_bad {(err > tol).sum()}"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# sort
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B", [1, 5, 64, 100, 1000, 4096])
+def test_sort_bit_exact(fmx, B):
+    pr = make_problem(MIXED_SIZES, 4, B, seed=B)
+    t = weights_table(fmx, MIXED_SIZES, 4, pr)
+    eng = fmx.FMEngine(t, max_batch=B)
+    idx_d, _, _ = eng.to_device(pr["idx"])
+    eng.sort(idx_d)
+    torch.cuda.synchronize()
+    got = eng.sorted.cpu().numpy().view(np.uint32)
+    Bp, bbits = eng.lib.fmx_sorted_width(B), eng.lib.fmx_sorted_bbits(B)
+    assert got.shape == (len(MIXED_SIZES), Bp)
+    for f in range(len(MIXED_SIZES)):
+        comp = (pr["idx"][:, f].astype(np.uint32) << np.uint32(bbits)) | np.arange(B, dtype=np.uint32)
+        want = np.full(Bp, 0xFFFFFFFF, dtype=np.uint32)
+        want[:B] = np.sort(comp)
+        np.testing.assert_array_equal(got[f], want)
+    assert int(eng.error.item()) == 0
+
+
+def test_out_of_range_index_is_flagged(fmx):
+    pr = make_problem(MIXED_SIZES, 4, 8, seed=1)
+    t = weights_table(fmx, MIXED_SIZES, 4, pr)
+    eng = fmx.FMEngine(t, max_batch=8)
+    bad = pr["idx"].copy()
+    bad[3, 0] = MIXED_SIZES[0]            # one past the end of field 0
+    idx_d, _, _ = eng.to_device(bad)
+    eng.forward(fmx.Hyper(**HYP), idx_d)
+    with pytest.raises(IndexError):
+        eng.check_error_flag()
+    eng.sort(idx_d)
+    with pytest.raises(IndexError):
+        eng.check_error_flag()
+    with pytest.raises(IndexError):
+        fmx.normalize_inputs(bad, np.ones_like(bad), len(MIXED_SIZES), MIXED_SIZES)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# forward
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [4, 10, 16, 24, 64])
+@pytest.mark.parametrize("real_x", [False, True])
+def test_forward_weights(fmx, k, real_x):
+    B = 37
+    pr = make_problem(MIXED_SIZES, k, B, seed=10 + k, real_x=real_x)
+    t = weights_table(fmx, MIXED_SIZES, k, pr)
+    eng = fmx.FMEngine(t, max_batch=B)
+    idx_d, xv_d, y_d = eng.to_device(pr["idx"], pr["x"], pr["y"])
+    x = pr["x"] if real_x else np.ones((B, len(MIXED_SIZES)), dtype=np.float32)
+    ref = orc.flat_forward(pr["V"], pr["w"], pr["bias"], pr["rows"], x)
+    for loss in ("logits", "sigmoid"):
+        eng.forward(fmx.Hyper(**HYP), idx_d, xv_d, y_d, loss=loss)
+        torch.cuda.synchronize()
+        S = eng.S[:B, :k].cpu().numpy()
+        smax = np.abs(ref["S"]).max()
+        close(S, ref["S"], 1e-5, 1e-6 * smax, "S")
+        assert (eng.S[:B, k:].cpu().numpy() == 0).all()
+        close(eng.bi[:B, :k].cpu().numpy(), ref["bi"], 1e-5, 2e-6 * smax * smax, "bi")
+        close(eng.first[:B].cpu().numpy(), ref["first"], 1e-6, 1e-8, "first")
+        close(eng.sfirst[:B].cpu().numpy(), ref["sfirst"], 1e-5, 1e-6, "sfirst")
+        close(eng.sbi[:B].cpu().numpy(), ref["sbi"], 1e-5, 4e-6 * smax * smax * k, "sbi")
+        z = eng.logit[:B].cpu().numpy()
+        close(z, ref["logit"], 1e-5, 4e-6 * smax * smax * k, "logit")
+        # loss / dz are checked against the oracle evaluated at the kernel's own logit (the epilogue itself)
+        close(eng.loss_b[:B].cpu().numpy(), orc.loss_value(z, pr["y"], loss), 1e-5, 1e-7, "loss")
+        close(eng.dz[:B].cpu().numpy(), orc.dloss_dlogit(z, pr["y"], loss, 1.0 / B), 1e-5, 1e-9, "dz")
+
+
+@pytest.mark.parametrize("k", [4, 16])
+def test_forward_ftrl_layout(fmx, k):
+    B = 50
+    pr = make_problem(MIXED_SIZES, k, B, seed=3, real_x=True)
+    st = ftrl_state(pr, HYP)
+    t = ftrl_table(fmx, MIXED_SIZES, k, st)
+    eng = fmx.FMEngine(t, max_batch=B)
+    idx_d, xv_d, y_d = eng.to_device(pr["idx"], pr["x"], pr["y"])
+    eng.forward(fmx.Hyper(**HYP), idx_d, xv_d, y_d, loss="logits")
+    torch.cuda.synchronize()
+    h = dict(alpha=HYP["alpha"], beta=HYP["beta"], l1=HYP["l1"], l2=HYP["l2"])
+    V = orc.ftrl_weight(st["zV"], st["nV"], **h)
+    w = orc.ftrl_weight(st["zw"], st["nw"], **h)
+    b = orc.ftrl_weight(st["zb"], st["nb"], **h)
+    assert (V == 0).any(), "the L1 dead zone must be exercised"
+    ref = orc.flat_forward(V, w, b, pr["rows"], pr["x"])
+    smax = np.abs(ref["S"]).max()
+    close(eng.S[:B, :k].cpu().numpy(), ref["S"], 1e-5, 2e-6 * smax, "S")
+    close(eng.logit[:B].cpu().numpy(), ref["logit"], 1e-5, 4e-6 * smax * smax * k + 1e-6, "logit")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# full step (sort + forward + update) vs the oracle's flat step
+# ---------------------------------------------------------------------------------------------------------
+def run_step_weights(fmx, sizes, k, B, rule, loss, seed, real_x=False, zipf=False, stride=None, n_steps=1):
+    pr = make_problem(sizes, k, B, seed, real_x=real_x, zipf=zipf)
+    t = weights_table(fmx, sizes, k, pr, stride)
+    eng = fmx.FMEngine(t, max_batch=B)
+    hyp = fmx.Hyper(**HYP)
+    idx_d, xv_d, y_d = eng.to_device(pr["idx"], pr["x"], pr["y"])
+    state = dict(V=pr["V"].copy(), w=pr["w"].copy(), bias=np.float32(pr["bias"]))
+    x = pr["x"] if real_x else np.ones((B, len(sizes)), dtype=np.float32)
+    outs = []
+    for _ in range(n_steps):
+        eng.step(hyp, rule, loss, idx_d, xv_d, y_d)
+        outs.append((orc.flat_fm_step(state, pr["rows"], x, pr["y"], loss, rule, dict(lr=HYP["lr"])),
+                     float(eng.loss_out.item())))
+    torch.cuda.synchronize()
+    eng.check_error_flag()
+    return pr, t, state, outs
+
+
+def check_weights_after(pr, t, state, out, rule, k):
+    V_new = t.rows[:, :k].cpu().numpy()
+    w_new = t.rows[:, t.kp].cpu().numpy()
+    touched = np.zeros(pr["R"], dtype=bool)
+    touched[out["urows"]] = True
+    # rows no sample touched are bit-identical
+    np.testing.assert_array_equal(V_new[~touched], pr["V"][~touched])
+    np.testing.assert_array_equal(w_new[~touched], pr["w"][~touched])
+    assert (t.rows[:, k:t.kp].cpu().numpy() == 0).all() and (t.rows[:, t.kp + 1:].cpu().numpy() == 0).all()
+    u = out["urows"]
+    gV, gw = out["dV"], out["dw"]
+    dV_hip, dw_hip = V_new[u] - pr["V"][u], w_new[u] - pr["w"][u]
+    dV_ref, dw_ref = state["V"][u] - pr["V"][u], state["w"][u] - pr["w"][u]
+    gmax = max(np.abs(gV).max(), 1e-30)
+    if rule == "sgd":
+        # delta = -lr * g: 1e-5 relative plus the cancellation floor of the fp32 subtraction (after - before)
+        close(dV_hip, dV_ref, 1e-5, 2e-6 * HYP["lr"] * gmax + 1.2e-7 * np.abs(pr["V"][u]), "dV")
+        close(dw_hip, dw_ref, 1e-5, 2e-6 * HYP["lr"] * np.abs(gw).max() + 1.2e-7 * np.abs(pr["w"][u]), "dw")
+    else:
+        # sign-like rule: a coordinate whose summed gradient is ~0 may legitimately step the other way
+        okV = np.abs(gV) > 1e-5 * gmax
+        okw = np.abs(gw) > 1e-5 * max(np.abs(gw).max(), 1e-30)
+        assert okV.mean() > 0.99
+        close(dV_hip[okV], dV_ref[okV], 1e-4, 1.2e-7 * np.abs(pr["V"][u][okV]) + 1e-9, "dV")
+        close(dw_hip[okw], dw_ref[okw], 1e-4, 1.2e-7 * np.abs(pr["w"][u][okw]) + 1e-9, "dw")
+    close(t.bias[0].item(), state["bias"], 1e-5, 1e-7, "bias")
+
+
+@pytest.mark.parametrize("rule", ["signadam", "sgd"])
+@pytest.mark.parametrize("B,k,real_x", [(1, 4, False), (7, 10, True), (64, 16, False), (300, 16, True),
+                                        (4096, 16, False), (2500, 10, False)])
+def test_step_weights_rules(fmx, rule, B, k, real_x):
+    loss = "logits" if B % 2 else "sigmoid"
+    pr, t, state, outs = run_step_weights(fmx, MIXED_SIZES, k, B, rule, loss, seed=B + k, real_x=real_x)
+    out, loss_hip = outs[0]
+    close(loss_hip, out["loss"], 1e-5, 1e-7, "mean loss")
+    check_weights_after(pr, t, state, out, rule, k)
+
+
+def test_step_zipf_and_custom_stride(fmx):
+    pr, t, state, outs = run_step_weights(fmx, MIXED_SIZES, 16, 1000, "sgd", "logits", seed=9, zipf=True, stride=20)
+    check_weights_after(pr, t, state, outs[0][0], "sgd", 16)
+
+
+@pytest.mark.parametrize("B,k", [(1, 4), (33, 16), (4096, 16)])
+def test_step_ftrl(fmx, B, k):
+    sizes = MIXED_SIZES
+    pr = make_problem(sizes, k, B, seed=77 + B, real_x=(B == 33))
+    st = ftrl_state(pr, HYP)
+    st0 = {kk: np.array(v, copy=True) for kk, v in st.items()}
+    t = ftrl_table(fmx, sizes, k, st)
+    eng = fmx.FMEngine(t, max_batch=B)
+    idx_d, xv_d, y_d = eng.to_device(pr["idx"], pr["x"], pr["y"])
+    eng.step(fmx.Hyper(**HYP), "ftrl", "logits", idx_d, xv_d, y_d)
+    torch.cuda.synchronize()
+    x = pr["x"] if pr["x"] is not None else np.ones((B, len(sizes)), dtype=np.float32)
+    h = dict(alpha=HYP["alpha"], beta=HYP["beta"], l1=HYP["l1"], l2=HYP["l2"])
+    out = orc.flat_fm_step(st, pr["rows"], x, pr["y"], "logits", "ftrl", h)
+    close(float(eng.loss_out.item()), out["loss"], 1e-5, 1e-7, "loss")
+    zV, nV, zw, nw = [a.numpy() for a in t.export_ftrl_state()]
+    touched = np.zeros(pr["R"], dtype=bool)
+    touched[out["urows"]] = True
+    np.testing.assert_array_equal(zV[~touched], st0["zV"][~touched])
+    np.testing.assert_array_equal(nV[~touched], st0["nV"][~touched])
+    u = out["urows"]
+    g2 = out["dV"].astype(np.float64) ** 2
+    # n += g^2 ; z += g - sigma w : compare the increments, with the subtraction's cancellation floor
+    close(nV[u] - st0["nV"][u], st["nV"][u] - st0["nV"][u], 3e-5, 1e-6 * g2.max() + 1.2e-7 * st0["nV"][u], "nV")
+    zs = np.abs(st["zV"][u] - st0["zV"][u]).max()
+    close(zV[u] - st0["zV"][u], st["zV"][u] - st0["zV"][u], 3e-5, 2e-6 * zs + 2.4e-7 * np.abs(st0["zV"][u]), "zV")
+    close(nw[u] - st0["nw"][u], st["nw"][u] - st0["nw"][u], 3e-5, 1e-6 * (out["dw"] ** 2).max() + 1.2e-7 * st0["nw"][u], "nw")
+    close(zw[u] - st0["zw"][u], st["zw"][u] - st0["zw"][u], 3e-5,
+          2e-6 * np.abs(st["zw"][u] - st0["zw"][u]).max() + 2.4e-7 * np.abs(st0["zw"][u]), "zw")
+    close(t.bias[0].item(), st["zb"], 1e-5, 1e-6, "zb")
+    close(t.bias[1].item(), st["nb"], 1e-5, 1e-7, "nb")
+
+
+def test_update_with_network_gradient(fmx):
+    """General form: G[b,d] = dz_bi[b] + gbi[b,d] with separate first-order coefficient (DeepFM / NFM callers)."""
+    sizes, k, B = MIXED_SIZES, 10, 257
+    pr = make_problem(sizes, k, B, seed=21, real_x=True)
+    t = weights_table(fmx, sizes, k, pr)
+    eng = fmx.FMEngine(t, max_batch=B)
+    hyp = fmx.Hyper(**HYP)
+    rng = np.random.default_rng(4)
+    dz_first = (rng.normal(size=B) * 0.1).astype(np.float32)
+    dz_bi = (rng.normal(size=B) * 0.1).astype(np.float32)
+    gbi = np.zeros((B, t.kp), dtype=np.float32)
+    gbi[:, :k] = rng.normal(size=(B, k)) * 0.1
+    idx_d, xv_d, _ = eng.to_device(pr["idx"], pr["x"])
+    eng.sort(idx_d)
+    eng.forward(hyp, idx_d, xv_d)
+    for use_dzbi in (True, False):
+        t.rows[:, :k] = torch.from_numpy(pr["V"]).cuda()
+        t.rows[:, t.kp] = torch.from_numpy(pr["w"]).cuda()
+        t.bias[0] = float(pr["bias"])
+        eng.update(hyp, "sgd", B, xv_d, torch.from_numpy(dz_first).cuda(),
+                   torch.from_numpy(dz_bi).cuda() if use_dzbi else None, torch.from_numpy(gbi).cuda(), with_loss=False)
+        torch.cuda.synchronize()
+        fw = orc.flat_forward(pr["V"], pr["w"], pr["bias"], pr["rows"], pr["x"])
+        G = gbi[:, :k] + (dz_bi[:, None] if use_dzbi else 0)
+        urows, dV, dw = orc.flat_row_gradients(pr["V"], pr["rows"], pr["x"], fw["S"], dz_first, G.astype(np.float32))
+        V_new = t.rows[:, :k].cpu().numpy()
+        w_new = t.rows[:, t.kp].cpu().numpy()
+        close(V_new[urows] - pr["V"][urows], -HYP["lr"] * dV, 1e-5,
+              2e-6 * HYP["lr"] * np.abs(dV).max() + 1.2e-7 * np.abs(pr["V"][urows]), "dV")
+        close(w_new[urows] - pr["w"][urows], -HYP["lr"] * dw, 1e-5,
+              2e-6 * HYP["lr"] * np.abs(dw).max() + 1.2e-7 * np.abs(pr["w"][urows]), "dw")
+        close(t.bias[0].item(), pr["bias"] - HYP["lr"] * dz_first.sum(dtype=np.float32), 1e-5, 1e-7, "bias")
+
+
+def test_step_is_deterministic(fmx):
+    res = []
+    for _ in range(2):
+        pr, t, state, outs = run_step_weights(fmx, MIXED_SIZES, 16, 4096, "signadam", "sigmoid", seed=5, zipf=True,
+                                              n_steps=3)
+        res.append((t.rows.cpu().numpy().copy(), t.bias.cpu().numpy().copy(), outs[-1][1]))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE.json full size: Criteo-39 vocabulary, k = 16, B = 4096
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rule", ["sgd", "ftrl"])
+def test_full_size_criteo(fmx, rule):
+    sizes, k, B = CRITEO_SIZES, 16, 4096
+    pr = make_problem(sizes, k, B, seed=2024)
+    hyp = fmx.Hyper(**HYP)
+    x = np.ones((B, len(sizes)), dtype=np.float32)
+    if rule == "sgd":
+        pr, t, state, outs = run_step_weights(fmx, sizes, k, B, "sgd", "logits", seed=2024)
+        close(outs[0][1], outs[0][0]["loss"], 1e-5, 1e-7, "loss")
+        check_weights_after(pr, t, state, outs[0][0], "sgd", k)
+        return
+    st = ftrl_state(pr, HYP)
+    st0 = {kk: np.array(v, copy=True) for kk, v in st.items()}
+    t = ftrl_table(fmx, sizes, k, st)
+    eng = fmx.FMEngine(t, max_batch=B)
+    idx_d, _, y_d = eng.to_device(pr["idx"], None, pr["y"])
+    eng.step(hyp, "ftrl", "logits", idx_d, None, y_d)
+    torch.cuda.synchronize()
+    h = dict(alpha=HYP["alpha"], beta=HYP["beta"], l1=HYP["l1"], l2=HYP["l2"])
+    out = orc.flat_fm_step(st, pr["rows"], x, pr["y"], "logits", "ftrl", h)
+    close(float(eng.loss_out.item()), out["loss"], 1e-5, 1e-7, "loss")
+    zV, nV, zw, nw = [a.numpy() for a in t.export_ftrl_state()]
+    touched = np.zeros(pr["R"], dtype=bool)
+    touched[out["urows"]] = True
+    # size-independent properties: untouched rows bit-identical, n never decreases, sortedness of every list
+    np.testing.assert_array_equal(zV[~touched], st0["zV"][~touched])
+    np.testing.assert_array_equal(nw[~touched], st0["nw"][~touched])
+    assert (nV >= st0["nV"]).all()
+    srt = eng.sorted.cpu().numpy().view(np.uint32)
+    assert (np.diff(srt.astype(np.int64), axis=1) >= 0).all()
+    u = out["urows"]
+    close(nV[u] - st0["nV"][u], st["nV"][u] - st0["nV"][u], 3e-5,
+          1e-6 * (out["dV"].astype(np.float64) ** 2).max() + 1.2e-7 * st0["nV"][u], "nV")
+    # the derived weights after the step agree
+    w_hip = orc.ftrl_weight(zV[u], nV[u], **h)
+    w_ref = orc.ftrl_weight(st["zV"][u], st["nV"][u], **h)
+    close(w_hip, w_ref, 2e-5, 2e-6 * np.abs(w_ref).max(), "V after")
+
+
+def test_stream_matches_repeated_steps(fmx):
+    """fmx_fm_stream over a pool == the same steps issued one by one; the timed variant returns kernel times."""
+    sizes, k, B, n_pool, n_steps = MIXED_SIZES, 16, 512, 3, 7
+    prs = [make_problem(sizes, k, B, seed=40 + j) for j in range(n_pool)]
+    hyp = fmx.Hyper(**HYP)
+    t1 = weights_table(fmx, sizes, k, prs[0])
+    e1 = fmx.FMEngine(t1, max_batch=B)
+    losses1 = []
+    for s in range(n_steps):
+        pr = prs[s % n_pool]
+        idx_d, _, y_d = e1.to_device(pr["idx"], None, pr["y"])
+        e1.step(hyp, "signadam", "logits", idx_d, None, y_d)
+        losses1.append(float(e1.loss_out.item()))
+    for timed in (False, True):
+        t2 = weights_table(fmx, sizes, k, prs[0])
+        e2 = fmx.FMEngine(t2, max_batch=B)
+        idx_pool = torch.from_numpy(np.stack([p["idx"] for p in prs])).cuda()
+        y_pool = torch.from_numpy(np.stack([p["y"] for p in prs])).cuda()
+        loss_out = torch.zeros(n_steps, device="cuda")
+        ms = e2.stream(hyp, "signadam", "logits", idx_pool, y_pool, n_steps, loss_out, timed=timed)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(t1.rows.cpu().numpy(), t2.rows.cpu().numpy())
+        np.testing.assert_array_equal(np.asarray(losses1, dtype=np.float32), loss_out.cpu().numpy())
+        if timed:
+            assert len(ms) == 3 and all(v > 0 for v in ms)
+
+
+def test_abi_rejects_bad_arguments(fmx):
+    pr = make_problem(MIXED_SIZES, 4, 8, seed=1)
+    t = weights_table(fmx, MIXED_SIZES, 4, pr)
+    eng = fmx.FMEngine(t, max_batch=8)
+    idx_d, _, y_d = eng.to_device(pr["idx"], None, pr["y"])
+    with pytest.raises(fmx._lib.FmxError) as ei:
+        eng.step(fmx.Hyper(**HYP), "ftrl", "logits", idx_d, None, y_d)     # FTRL rule on a weights-layout table
+    assert ei.value.code == fmx._lib.ERR_ARG
+    big = fmx.FlatTable([1 << 22, 5], 4)                                      # 22 index bits + 12 sample bits > 32
+    e2 = fmx.FMEngine(big, max_batch=4096)
+    idx = torch.zeros((4096, 2), dtype=torch.int32, device="cuda")
+    with pytest.raises(fmx._lib.FmxError) as ei:
+        e2.sort(idx)
+    assert ei.value.code == fmx._lib.ERR_UNSUPPORTED
