@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- online FM + FTRL-proximal on synthetic Criteo-39 (BASELINE.json configs[1]/[2]).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one mini-batch: sort the batch's occurrences, gather + bi-interaction
+forward with the fused BCE loss, row-reduced backward + fused FTRL-proximal update of every touched row.  Inputs (a
+pool of batches) and the table are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "fm-for-online-recommendation_amd"))
+sys.path.insert(0, ROOT)
+
+CRITEO_SIZES = [63, 113, 126, 51, 224, 148, 100, 79, 104, 9, 32, 57, 82, 1457, 555, 176373, 129683, 305, 19, 11887,
+                632, 3, 41738, 5170, 175446, 3170, 27, 11356, 165602, 10, 4641, 2030, 4, 172761, 18, 15, 57903, 86,
+                44549]   # reference main_experiment.py:56-58; sum = 1,006,628 rows
+K_EMB, BATCH, N_POOL, SEED = 16, 4096, 16, 20240922
+HYPER = dict(lr=0.01, eps=1e-8, alpha=0.05, beta=1.0, l1=0.0, l2=1e-4)
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic bytes per sample (DESIGN.md "Byte accounting"; fp32, int32 indices, 17 coordinates per row)
+F = len(CRITEO_SIZES)
+BYTES_STEP_FTRL = 4 * F + 2 * (2 * 68 * F) + 8                       # 10,772: SURVEY.md section 8(d)
+BYTES_K_FORWARD = 4 * F + 2 * 68 * F + 4 + 68 + 4                    # idx + (z,n) rows + y + S,dz out + loss
+BYTES_K_UPDATE = 4 * F + 2 * (2 * 68 * F) + 68                       # sorted list + rows read + rows written + S,dz in
+BYTES_K_SORT = 4 * F + 4 * F                                         # idx in, sorted out
+
+
+def synth_pool(n_pool, B, sizes, seed, zipf=False):
+    """Counter-based (Philox) synthetic Criteo-shaped stream: batch j is a pure function of (seed, j)."""
+    idx = np.empty((n_pool, B, len(sizes)), dtype=np.int32)
+    y = np.empty((n_pool, B), dtype=np.float32)
+    for j in range(n_pool):
+        rng = np.random.Generator(np.random.Philox(key=seed + j))
+        for f, s in enumerate(sizes):
+            if zipf:
+                idx[j, :, f] = np.minimum(rng.zipf(1.05, size=B) - 1, s - 1)
+            else:
+                idx[j, :, f] = rng.integers(0, s, size=B)
+        y[j] = (rng.uniform(size=B) < 0.3)
+    return idx, y
+
+
+def cpu_baseline(idx_pool, y_pool, sizes, seconds=15.0):
+    """The oracle's flat FTRL step (numpy port of the same algorithm), timed on this host on a bounded sample."""
+    from oracle import fm_oracle as orc
+    rng = np.random.default_rng(1)
+    R = int(sum(sizes))
+    h = {k: HYPER[k] for k in ("alpha", "beta", "l1", "l2")}
+    V0 = (rng.normal(size=(R, K_EMB)) * 0.01).astype(np.float32)
+    st = dict(zV=orc.ftrl_z_for_weight(V0, **h), nV=np.zeros((R, K_EMB), np.float32), zw=np.zeros(R, np.float32),
+              nw=np.zeros(R, np.float32), zb=np.float32(0), nb=np.float32(0))
+    offs = np.concatenate([[0], np.cumsum(sizes)])[:-1].astype(np.int64)
+    x = np.ones(idx_pool.shape[1:], dtype=np.float32)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        j = n % idx_pool.shape[0]
+        orc.flat_fm_step(st, idx_pool[j].astype(np.int64) + offs[None, :], x, y_pool[j], "logits", "ftrl", h)
+        n += 1
+        if time.perf_counter() - t0 > seconds or n >= 64:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=n * idx_pool.shape[1] / dt, unit="samples/s", cores=1, kind="port",
+                sample=f"{n} steps of B={idx_pool.shape[1]} of the same stream, oracle/fm_oracle.py flat_fm_step (numpy, 1 thread)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--zipf", action="store_true", help="Zipf(1.05) indices instead of uniform (secondary workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--row-stride", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import fmx
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- resident state: FTRL table (z, n) with V ~ N(0, 0.01) folded into z, first-order weights 0 ----
+    table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="ftrl", device=dev,
+                          row_stride=args.row_stride if args.row_stride else None)
+    g = torch.Generator(device=dev).manual_seed(SEED)
+    w0 = torch.randn((table.n_rows, K_EMB), generator=g, device=dev) * 0.01
+    d0 = HYPER["beta"] / HYPER["alpha"] + HYPER["l2"]
+    table.rows[:, :K_EMB] = -w0 * d0 - torch.sign(w0) * HYPER["l1"]
+    del w0
+    hyper = fmx.Hyper(**HYPER)
+    eng = fmx.FMEngine(table, max_batch=BATCH)
+    idx_np, y_np = synth_pool(N_POOL, BATCH, CRITEO_SIZES, SEED + 1000 * rank, zipf=args.zipf)
+    idx_pool = torch.from_numpy(idx_np).to(dev)
+    y_pool = torch.from_numpy(y_np).to(dev)
+    loss_buf = torch.zeros(max(args.steps, args.warmup, 1), device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up, then EXACTLY K timed steps ----
+    eng.stream(hyper, "ftrl", "logits", idx_pool, y_pool, args.warmup, loss_buf)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = eng.stream(hyper, "ftrl", "logits", idx_pool, y_pool, args.steps, loss_buf, timed=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.check_error_flag()
+    losses = loss_buf[:args.steps].cpu().numpy()
+    assert np.isfinite(losses).all(), "non-finite loss in the timed region"
+
+    # the same K steps without per-launch events (informational: what the event bracketing costs)
+    barrier()
+    t1 = time.perf_counter()
+    eng.stream(hyper, "ftrl", "logits", idx_pool, y_pool, args.steps, loss_buf, timed=False)
+    barrier()
+    dt_noev = time.perf_counter() - t1
+
+    if world > 1:
+        tt = torch.tensor([dt, dt_noev], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, dt_noev = float(tt[0]), float(tt[1])
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- HBM-read ceiling on this GPU, same run ----
+    probe = torch.empty(1 << 30, dtype=torch.float32, device=dev)      # 4 GiB
+    probe.normal_()
+    sink = torch.zeros(1, device=dev)
+    lib = fmx._lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        fmx._lib.check(lib.fmx_stream_read(probe.data_ptr(), probe.numel() * 4, sink.data_ptr(), st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        fmx._lib.check(lib.fmx_stream_read(probe.data_ptr(), probe.numel() * 4, sink.data_ptr(), st))
+    e1.record()
+    torch.cuda.synchronize()
+    stream_gbps = 5 * probe.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del probe
+
+    sort_ms, fwd_ms, upd_ms = [v / args.steps for v in kernel_ms]
+    samples = args.steps * BATCH * world
+    value = samples / dt
+    ach = BYTES_K_UPDATE * BATCH / (upd_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_fm_update_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "samples/sec online-FM (Criteo-39-field, k=16) FTRL-proximal",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "online FM fwd+bwd + fused FTRL-proximal row update, synthetic Criteo-39 "
+                               f"(R=1,006,628 rows, k=16, B={BATCH} per GPU, {'Zipf(1.05)' if args.zipf else 'uniform'} indices, "
+                               "labels Bernoulli(0.3)); BASELINE.json configs[1]+[2]",
+                   "global_batch": BATCH * world, "row_stride_bytes": table.row_stride * 4,
+                   "hyper": HYPER, "pool_batches": N_POOL},
+        "roofline": {"bound": "hbm", "kernel": "k_fm_update", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": BYTES_K_UPDATE * BATCH, "avg_launch_ms": upd_ms},
+        "kernels_ms_per_step": {"k_sort_occ": sort_ms, "k_fm_forward": fwd_ms, "k_fm_update": upd_ms},
+        "step_algorithmic": {"bytes_per_sample": BYTES_STEP_FTRL, "GBps": value / world * BYTES_STEP_FTRL / 1e9,
+                             "frac_of_peak": value / world * BYTES_STEP_FTRL / 1e9 / HBM_PEAK_GBPS,
+                             "frac_of_measured_stream_read": value / world * BYTES_STEP_FTRL / 1e9 / stream_gbps},
+        "measured_stream_read_GBps": stream_gbps,
+        "ms_per_step_without_events": dt_noev / args.steps * 1e3,
+        "samples_per_s_without_events": samples / dt_noev,
+        "final_loss": float(losses[-1]),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(idx_np, y_np, CRITEO_SIZES)
+        out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

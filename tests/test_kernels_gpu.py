@@ -205,11 +205,17 @@ def check_weights_after(pr, t, state, out, rule, k):
         close(dw_hip, dw_ref, 1e-5, 2e-6 * HYP["lr"] * np.abs(gw).max() + 1.2e-7 * np.abs(pr["w"][u]), "dw")
     else:
         # sign-like rule: a coordinate whose summed gradient is ~0 may legitimately step the other way
-        okV = np.abs(gV) > 1e-5 * gmax
-        okw = np.abs(gw) > 1e-5 * max(np.abs(gw).max(), 1e-30)
-        assert okV.mean() > 0.99
-        close(dV_hip[okV], dV_ref[okV], 1e-4, 1.2e-7 * np.abs(pr["V"][u][okV]) + 1e-9, "dV")
-        close(dw_hip[okw], dw_ref[okw], 1e-4, 1.2e-7 * np.abs(pr["w"][u][okw]) + 1e-9, "dw")
+        # p -= lr g / (|g| + eps) is sign-like: fp32 evaluation leaves ~3e-7 * aV of noise in g (aV = rounding
+        # scale), which moves the step by lr * eps * noise / (|g| + eps)^2; a coordinate with |g| inside the noise may
+        # legitimately step the other way and is skipped
+        lr, eps = HYP["lr"], HYP["eps"]
+        nV, nw = 3e-7 * out["aV"], 3e-7 * out["aw"]
+        okV, okw = np.abs(gV) > 4 * nV, np.abs(gw) > 4 * nw
+        assert okV.mean() > 0.99 and okw.mean() > 0.99
+        tolV = lr * eps * nV / (np.abs(gV) + eps) ** 2 + 1.2e-7 * np.abs(pr["V"][u]) + 1e-9
+        tolw = lr * eps * nw / (np.abs(gw) + eps) ** 2 + 1.2e-7 * np.abs(pr["w"][u]) + 1e-9
+        close(dV_hip[okV], dV_ref[okV], 1e-5, tolV[okV], "dV")
+        close(dw_hip[okw], dw_ref[okw], 1e-5, tolw[okw], "dw")
     close(t.bias[0].item(), state["bias"], 1e-5, 1e-7, "bias")
 
 
