@@ -1,0 +1,374 @@
+"""Shared machinery of the five embedding-table online models (hot path A).
+
+The reference implements each class as ~39 x 2 nn.Embedding gathers, Python sums, autograd into dense table-sized
+gradients and a fresh torch.optim.Adam over every parameter per call (reference models/models_online_deep/*.py).
+Here the tables live in one fmx.FlatTable in HBM and every table-touching step is three gfx950 kernels
+(sort occurrences -> gather + bi-interaction forward -> row-reduced backward with the fused per-row update);
+PyTorch is left with the tiny dense MLP on top of the bi-interaction vector and with plumbing.
+
+Reference behaviours kept on purpose (SURVEY.md sections 2a, 3.3, 7 "hard parts"; all are results-bearing):
+  * a fresh Adam per call == p -= lr * g / (|g| + 1e-8) on coordinates with a non-zero gradient ('signadam' rule);
+  * the loss is BCE-with-logits of sigmoid(logit) in some (class, method) pairs ("double sigmoid");
+  * DeepFM evaluates second_order twice, so its table gradient is the FM-term gradient plus the MLP-input gradient;
+  * the ONN classes' fit() trains only the hidden layers and alpha (Hedge); their predict() applies a second sigmoid;
+  * `bias` and `n` appear in state_dict(); the oracle is the reference's CPU behaviour, where `bias` IS trained.
+There is no CPU path: constructing a model without a ROCm GPU raises.
+"""
+from time import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import fmx
+
+
+class _FieldView:
+    """Stands where the reference has an nn.Embedding: `.weight` is a strided view into the flat table."""
+
+    def __init__(self, table, f, second):
+        self._table, self._f, self._second = table, f, second
+
+    @property
+    def weight(self):
+        return self._table.field_V(self._f) if self._second else self._table.field_w(self._f)
+
+
+class OnlineFMBase(nn.Module):
+    _name = "FMAdam"
+    _has_mlp = False          # DeepFM / NFM: relu MLP on the bi-interaction vector
+    _fm_term_in_forward = True  # False for NFM: forward() has no sum_d bi_d term
+    _onn = False
+    _loss_update_embedding = "logits"
+    _loss_fit = "sigmoid"
+
+    def __init__(self, feature_sizes, embedding_size=4, num_hidden_layers=0, neuron_per_hidden_layer=0, batch_size=1,
+                 num_classes=1, b=0.99, n=0.01, s=0.2, use_cuda=True, update_rule="signadam", ftrl=None):
+        super().__init__()
+        if not (use_cuda and torch.cuda.is_available()):
+            raise RuntimeError(f"{self._name}: this build runs the hot path in gfx950 kernels only -- it needs use_cuda=True "
+                               "and a ROCm GPU (there is no CPU or PyTorch fallback; use the reference for CPU runs)")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.field_size = len(feature_sizes)
+        self.feature_sizes = feature_sizes
+        self.embedding_size = embedding_size
+        self.num_hidden_layers = num_hidden_layers
+        self.neuron_per_hidden_layer = neuron_per_hidden_layer
+        self.batch_size = batch_size
+        self.num_classes = num_classes
+        self.dtype = torch.long
+        self.update_rule = update_rule
+        if update_rule not in ("signadam", "sgd", "ftrl"):
+            raise ValueError(update_rule)
+
+        # ---- parameter initialisation in the reference's RNG order (reference fm_adam.py:26-32,
+        #      deepfm_onn.py:30-46), so that the same torch seed gives the same model ----
+        if self._onn:
+            bias0 = torch.rand(1)
+            self.b = torch.nn.Parameter(torch.tensor(b))
+            self.s = torch.nn.Parameter(torch.tensor(s), requires_grad=False)
+        else:
+            bias0 = torch.tensor(b)
+        self.n = torch.nn.Parameter(torch.tensor(n), requires_grad=False)
+        first = [nn.Embedding(fs, 1).weight.data for fs in feature_sizes]
+        second = [nn.Embedding(fs, embedding_size).weight.data for fs in feature_sizes]
+        self._bias_shape = tuple(bias0.shape)
+
+        self._ftrl = dict(alpha=0.05, beta=1.0, l1=0.0, l2=0.0)
+        if ftrl:
+            self._ftrl.update(ftrl)
+        self._table = fmx.FlatTable(feature_sizes, embedding_size, layout="ftrl" if update_rule == "ftrl" else "weights",
+                                    device=self.device)
+        self._load_weights(first, second, bias0)
+        del first, second
+        self._engine = fmx.FMEngine(self._table, max_batch=max(int(batch_size), 64))
+        self._hyper = fmx.Hyper(lr=float(n), eps=1e-8, **self._ftrl)
+
+        layers = []
+        if self._has_mlp:
+            layers.append(nn.Linear(embedding_size, neuron_per_hidden_layer))
+            for _ in range(num_hidden_layers - 1):
+                layers.append(nn.Linear(neuron_per_hidden_layer, neuron_per_hidden_layer))
+            self.hidden_layers = nn.ModuleList(layers).to(self.device)
+        if self._onn:
+            # a plain device tensor (on a GPU the reference's Parameter(...).to(device) is one too)
+            self.alpha = torch.full((num_hidden_layers,), 1 / (num_hidden_layers + 1), dtype=torch.float32,
+                                    device=self.device)
+        self.first_order_embeddings = [_FieldView(self._table, f, False) for f in range(self.field_size)]
+        self.second_order_embeddings = [_FieldView(self._table, f, True) for f in range(self.field_size)]
+
+    # ------------------------------------------------------------------------------------------------------
+    # table <-> reference-shaped weights
+    # ------------------------------------------------------------------------------------------------------
+    def _load_weights(self, first, second, bias):
+        t = self._table
+        bias = float(torch.as_tensor(bias).reshape(-1)[0])
+        if t.layout == "weights":
+            t.load_reference(first, second)
+            t.bias[0] = bias
+            return
+        # FTRL-proximal keeps (z, n) only: start from n = 0 and the z that reproduces the given weights
+        h = self._ftrl
+        d0 = h["beta"] / h["alpha"] + h["l2"]
+        V = torch.cat([torch.as_tensor(x, dtype=torch.float32) for x in second])
+        w = torch.cat([torch.as_tensor(x, dtype=torch.float32).reshape(-1) for x in first])
+        t.load_ftrl_state(-V * d0 - torch.sign(V) * h["l1"], torch.zeros_like(V), -w * d0 - torch.sign(w) * h["l1"],
+                          torch.zeros_like(w))
+        t.bias[0] = -bias * d0 - float(np.sign(bias)) * h["l1"]
+        t.bias[1] = 0.0
+
+    def _export_weights(self):
+        t = self._table
+        if t.layout == "weights":
+            first, second = t.export_reference()
+            return first, second, t.bias[0].detach().cpu()
+        h = self._ftrl
+        zV, nV, zw, nw = t.export_ftrl_state()
+
+        def wt(z, n):
+            w = -(z - torch.sign(z) * h["l1"]) / ((h["beta"] + torch.sqrt(n)) / h["alpha"] + h["l2"])
+            return torch.where(z.abs() <= h["l1"], torch.zeros_like(w), w)
+        V, w = wt(zV, nV), wt(zw, nw)
+        offs = t.offsets_host
+        first = [w[int(offs[f]):int(offs[f + 1])].reshape(-1, 1).clone() for f in range(t.n_fields)]
+        second = [V[int(offs[f]):int(offs[f + 1])].clone() for f in range(t.n_fields)]
+        zb = t.bias.detach().cpu()
+        return first, second, wt(zb[0:1], zb[1:2])[0]
+
+    @property
+    def bias(self):
+        zb = self._table.bias
+        if self._table.layout == "weights":
+            return zb[0].reshape(self._bias_shape)
+        h = self._ftrl                       # FTRL layout: the bias is derived from its (z, n) pair
+        w = -(zb[0] - torch.sign(zb[0]) * h["l1"]) / ((h["beta"] + torch.sqrt(zb[1])) / h["alpha"] + h["l2"])
+        return torch.where(zb[0].abs() <= h["l1"], torch.zeros_like(w), w).reshape(self._bias_shape)
+
+    def state_dict(self, *args, **kwargs):
+        """The reference's keys and shapes: first_order_embeddings.{i}.weight [size_i,1],
+        second_order_embeddings.{i}.weight [size_i,k], hidden_layers.{j}.weight/.bias, bias, n (+ b, s, alpha)."""
+        first, second, bias = self._export_weights()
+        sd = {"bias": bias.reshape(self._bias_shape).clone()}
+        if self._onn:
+            sd["b"] = self.b.detach().clone()
+        sd["n"] = self.n.detach().clone()
+        if self._onn:
+            sd["s"] = self.s.detach().clone()
+        for i in range(self.field_size):
+            sd[f"first_order_embeddings.{i}.weight"] = first[i]
+        for i in range(self.field_size):
+            sd[f"second_order_embeddings.{i}.weight"] = second[i]
+        if self._has_mlp:
+            for j, layer in enumerate(self.hidden_layers):
+                sd[f"hidden_layers.{j}.weight"] = layer.weight.detach().cpu().clone()
+                sd[f"hidden_layers.{j}.bias"] = layer.bias.detach().cpu().clone()
+        if self._onn:
+            sd["alpha"] = self.alpha.detach().cpu().clone()
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = {k: torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v) for k, v in state_dict.items()}
+        want = set(self.state_dict().keys())
+        if strict and set(sd.keys()) != want:
+            raise RuntimeError(f"state_dict keys differ: missing {sorted(want - set(sd))}, unexpected {sorted(set(sd) - want)}")
+        first = [sd[f"first_order_embeddings.{i}.weight"].float().cpu() for i in range(self.field_size)]
+        second = [sd[f"second_order_embeddings.{i}.weight"].float().cpu() for i in range(self.field_size)]
+        self._load_weights(first, second, sd["bias"].float().cpu())
+        with torch.no_grad():
+            self.n.copy_(sd["n"].float().cpu())
+            self._hyper = fmx.Hyper(lr=float(self.n), eps=1e-8, **self._ftrl)
+            if self._has_mlp:
+                for j, layer in enumerate(self.hidden_layers):
+                    layer.weight.copy_(sd[f"hidden_layers.{j}.weight"].float().to(self.device))
+                    layer.bias.copy_(sd[f"hidden_layers.{j}.bias"].float().to(self.device))
+            if self._onn:
+                self.b.copy_(sd["b"].float().cpu())
+                self.s.copy_(sd["s"].float().cpu())
+                self.alpha = sd["alpha"].float().clone().to(self.device)
+
+    # pickle support (reference main_experiment.py:160-162 pickles the whole model): tensors go through the CPU
+    def __getstate__(self):
+        return {"ctor": dict(feature_sizes=list(self.feature_sizes), embedding_size=self.embedding_size,
+                             num_hidden_layers=self.num_hidden_layers,
+                             neuron_per_hidden_layer=self.neuron_per_hidden_layer, batch_size=self.batch_size,
+                             num_classes=self.num_classes, update_rule=self.update_rule, ftrl=dict(self._ftrl)),
+                "cls": self._name, "state_dict": {k: v.cpu() for k, v in self.state_dict().items()}}
+
+    def __setstate__(self, state):
+        ctor = state["ctor"]
+        OnlineFMBase.__init__(self, ctor["feature_sizes"], embedding_size=ctor["embedding_size"],
+                              num_hidden_layers=ctor["num_hidden_layers"],
+                              neuron_per_hidden_layer=ctor["neuron_per_hidden_layer"], batch_size=ctor["batch_size"],
+                              num_classes=ctor["num_classes"], update_rule=ctor["update_rule"], ftrl=ctor["ftrl"])
+        self.load_state_dict(state["state_dict"])
+
+    # ------------------------------------------------------------------------------------------------------
+    # forward pieces (reference deepfm_adam.py:46-89)
+    # ------------------------------------------------------------------------------------------------------
+    def _inputs(self, Xi, Xv, Y=None):
+        idx, xv = fmx.normalize_inputs(Xi, Xv, self.field_size, self.feature_sizes)
+        return self._engine.to_device(idx, xv, Y)
+
+    def _fm_forward(self, Xi, Xv):
+        idx_d, xv_d, _ = self._inputs(Xi, Xv)
+        B = self._engine.forward(self._hyper, idx_d, xv_d)
+        return B
+
+    def first_order(self, Xi, Xv):
+        B = self._fm_forward(Xi, Xv)
+        return self._engine.first[:B].clone()
+
+    def second_order(self, Xi, Xv):
+        B = self._fm_forward(Xi, Xv)
+        return self._engine.bi[:B, :self.embedding_size].clone()
+
+    def forward_fm(self, Xi, Xv):
+        B = self._fm_forward(Xi, Xv)
+        return self._engine.logit[:B].clone().reshape(self._logit_shape(B))
+
+    def _logit_shape(self, B):
+        return (B,)
+
+    def _mlp(self, x):
+        acts = []
+        for layer in self.hidden_layers:
+            x = F.relu(layer(x))
+            acts.append(x)
+        return acts
+
+    def _base_logit(self, B):
+        e = self._engine
+        if self._fm_term_in_forward:
+            return e.logit[:B]
+        return e.sfirst[:B] + self.bias.reshape(-1)[0]
+
+    def forward(self, Xi, Xv):
+        B = self._fm_forward(Xi, Xv)
+        e = self._engine
+        with torch.no_grad():
+            if not self._has_mlp:
+                return e.logit[:B].clone()
+            acts = self._mlp(e.bi[:B, :self.embedding_size])
+            base = self._base_logit(B)
+            if not self._onn:
+                return base + acts[-1].sum(1)
+            layers = torch.stack([torch.sigmoid(base + a.sum(1)) for a in acts])
+            return layers[-1], layers
+
+    # ------------------------------------------------------------------------------------------------------
+    # training steps
+    # ------------------------------------------------------------------------------------------------------
+    def _fm_step(self, Xi, Xv, Y, loss_kind):
+        idx_d, xv_d, y_d = self._inputs(Xi, Xv, Y)
+        if y_d.numel() != idx_d.shape[0]:
+            raise ValueError(f"Target size ({y_d.numel()}) must be the same as input size ({idx_d.shape[0]})")
+        self._engine.step(self._hyper, self.update_rule, loss_kind, idx_d, xv_d, y_d)
+        return self._engine.loss_out[0].clone()
+
+    def update_embedding(self, Xi, Xv, Y):
+        """One mini-batch step on forward_fm (reference fm_adam.py:56-69); returns the loss tensor."""
+        self.train()
+        return self._fm_step(Xi, Xv, Y, self._loss_update_embedding)
+
+    def fit(self, Xi, Xv, Y):
+        self.train()
+        if not self._has_mlp:
+            self._fm_step(Xi, Xv, Y, self._loss_fit)
+            return
+        if self._onn:
+            self._fit_hedge(Xi, Xv, Y)
+            return
+        # DeepFM / NFM (reference deepfm_adam.py:106-119, nfm_adam.py:105-118): tables through the kernels,
+        # the MLP through autograd, every parameter updated by the fresh-Adam rule
+        idx_d, xv_d, y_d = self._inputs(Xi, Xv, Y)
+        e, k = self._engine, self.embedding_size
+        e.sort(idx_d)
+        B = e.forward(self._hyper, idx_d, xv_d)
+        bi = e.bi[:B, :k].detach().clone().requires_grad_(True)
+        base = self._base_logit(B).detach().clone().requires_grad_(True)
+        for p in self.hidden_layers.parameters():
+            p.grad = None
+        out = base + self._mlp(bi)[-1].sum(1)
+        if self._loss_fit == "sigmoid":
+            loss = F.binary_cross_entropy_with_logits(torch.sigmoid(out), y_d)
+        else:
+            loss = F.binary_cross_entropy_with_logits(out, y_d)
+        loss.backward()
+        dz = base.grad.contiguous()
+        gbi = bi.grad
+        if k != self._table.kp:
+            gbi = F.pad(gbi, (0, self._table.kp - k))
+        gbi = gbi.contiguous()
+        e.update(self._hyper, self.update_rule, B, xv_d, dz, dz if self._fm_term_in_forward else None, gbi,
+                 with_loss=False)
+        # hidden layers: literally the reference's optimizer (a new Adam, first step)
+        torch.optim.Adam(self.hidden_layers.parameters(), lr=float(self.n)).step()
+
+    def _fit_hedge(self, Xi, Xv, Y):
+        """Hedge backprop (reference deepfm_onn.py:109-154): hidden layers and alpha only.  Since
+        d(loss_i)/d(layer j) = 0 for j > i, the reference's alpha-weighted accumulation over L backward passes is the
+        gradient of sum_i alpha_i * loss_i, taken here in ONE backward pass over the MLP."""
+        idx_d, xv_d, y_d = self._inputs(Xi, Xv, Y)
+        B = idx_d.shape[0]
+        if B != self.batch_size or y_d.numel() != self.batch_size:
+            raise RuntimeError(f"shape '[{self.batch_size}]' is invalid for input of size {B}")
+        e, k = self._engine, self.embedding_size
+        e.forward(self._hyper, idx_d, xv_d, want_first=False)
+        base = self._base_logit(B).detach()
+        for p in self.hidden_layers.parameters():
+            p.grad = None
+        acts = self._mlp(e.bi[:B, :k].detach())
+        losses = torch.stack([F.binary_cross_entropy(torch.sigmoid(base + a.sum(1)), y_d) for a in acts])
+        alpha = self.alpha.detach()
+        (alpha * losses).sum().backward()
+        with torch.no_grad():
+            n = float(self.n)
+            for layer in self.hidden_layers:
+                layer.weight -= n * layer.weight.grad
+                layer.bias -= n * layer.bias.grad
+            bdev = self.b.detach().to(self.device)
+            a = alpha * torch.pow(bdev, losses.detach())
+            a = torch.maximum(a, (self.s.detach() / self.num_hidden_layers).to(self.device))
+            self.alpha = a / a.sum()
+
+    # ------------------------------------------------------------------------------------------------------
+    # inference / online protocol (reference fm_adam.py:84-119)
+    # ------------------------------------------------------------------------------------------------------
+    def predict(self, Xi, Xv):
+        self.eval()
+        out = self.forward(Xi, Xv)
+        if isinstance(out, tuple):
+            out = out[0]
+        pred = torch.sigmoid(out).cpu()
+        return pred.data.numpy() > 0.5
+
+    def run_experiment(self, data_Xi, data_Xv, data_Y):
+        data_size = len(data_Y)
+        confusion_matrix = {"tp": 0, "fp": 0, "tn": 0, "fn": 0}
+        accuracy, roc = [], []
+        start = time()
+        for i in range(data_size):
+            pred = self.predict(data_Xi[i], data_Xv[i])
+            self.fit([data_Xi[i]], [data_Xv[i]], [data_Y[i]])
+            hit = bool(pred == data_Y[i])
+            if data_Y[i] == 1:
+                confusion_matrix["tp" if hit else "fn"] += 1
+            else:
+                confusion_matrix["tn" if hit else "fp"] += 1
+            if i % 1000 == 0 or i == data_size - 1:
+                tpr = confusion_matrix["tp"] / (confusion_matrix["tp"] + confusion_matrix["fn"] + 1e-16)
+                fpr = confusion_matrix["fp"] / (confusion_matrix["fp"] + confusion_matrix["tn"] + 1e-16)
+                roc.append({"tpr": tpr, "fpr": fpr})
+                accuracy.append((confusion_matrix["tp"] + confusion_matrix["tn"]) / (i + 1) * 100)
+        time_elapsed = time() - start
+        return time_elapsed, accuracy[-1], roc[-1], confusion_matrix
+
+    def __str__(self):
+        s = f"{self._name}-Feature_Sizes{self.feature_sizes}-Embedding_Sizes{self.embedding_size}-"
+        if self._has_mlp:
+            s += f"Num_Hidden_Layers{self.num_hidden_layers}-Neuron_Per_Hidden_Layer{self.neuron_per_hidden_layer}-"
+        s += f"Num_Classes{self.num_classes}"
+        if self._onn:
+            s += f"-N{self.n}"
+        return s

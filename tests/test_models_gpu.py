@@ -1,0 +1,197 @@
+"""Class-level parity on the GPU: the drop-in classes (models.models_online_deep.*) against the golden fixtures the
+imported reference produced (tests/golden/make_golden.py) and against the oracle for the rules the reference lacks."""
+import io
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fm_oracle as orc
+from helpers import CLASS_NAMES, TAGS, assert_close, assert_state_close, load_model_fixture, sub
+
+pytestmark = pytest.mark.gpu
+RT = 1e-5
+
+
+def build(name, meta, batch_size, **extra):
+    from models.models_online_deep.fm_adam import FMAdam
+    from models.models_online_deep.deepfm_adam import DeepFMAdam
+    from models.models_online_deep.nfm_adam import NFMAdam
+    from models.models_online_deep.deepfm_onn import DeepFMOnn
+    from models.models_online_deep.nfm_onn import NFMOnn
+    cls = dict(FMAdam=FMAdam, DeepFMAdam=DeepFMAdam, NFMAdam=NFMAdam, DeepFMOnn=DeepFMOnn, NFMOnn=NFMOnn)[name]
+    fs, k, L, H, n = meta["feature_sizes"], meta["k"], meta["L"], meta["H"], meta["n"]
+    if name == "FMAdam":
+        return cls(fs, embedding_size=k, n=n, **extra)
+    if name == "NFMAdam":
+        return cls(fs, embedding_size=k, num_hidden_layers=L, neuron_per_hidden_layer=H, n=n, **extra)
+    return cls(fs, embedding_size=k, num_hidden_layers=L, neuron_per_hidden_layer=H, batch_size=batch_size, n=n, **extra)
+
+
+def sd_np(model):
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("name", CLASS_NAMES)
+def test_same_seed_same_model(name, tag):
+    """The constructors draw from the torch RNG in the reference's order: same seed => identical parameters."""
+    z, meta = load_model_fixture(name, tag)
+    torch.manual_seed(meta["seed"])
+    m = build(name, meta, meta["B2"])
+    sd, ref = sd_np(m), sub(z, "A/sd0")
+    assert set(sd) == set(ref)
+    for k in ref:
+        np.testing.assert_array_equal(sd[k], ref[k], err_msg=k)
+    torch.manual_seed(meta["seed"] + 1)
+    mb = build(name, meta, 1)
+    assert str(mb) == meta["str"]
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("name", CLASS_NAMES)
+def test_forward_pieces_vs_reference(name, tag):
+    z, meta = load_model_fixture(name, tag)
+    m = build(name, meta, meta["B2"])
+    m.load_state_dict(sub(z, "A/sd0"))
+    for j in (1, 2):
+        Xi, Xv = z[f"A/Xi{j}"].tolist(), z[f"A/Xv{j}"].tolist()
+        if name != "FMAdam":
+            assert_close(m.first_order(Xi, Xv).cpu().numpy(), z[f"A/first_order{j}"], RT, 1e-7, "first_order")
+            assert_close(m.second_order(Xi, Xv).cpu().numpy(), z[f"A/second_order{j}"], RT, 4e-6, "second_order")
+            assert_close(m.forward_fm(Xi, Xv).cpu().numpy(), z[f"A/forward_fm{j}"], RT, 2e-5, "forward_fm")
+        out = m.forward(Xi, Xv)
+        if isinstance(out, tuple):
+            assert_close(out[0].cpu().numpy(), z[f"A/forward{j}"], RT, 1e-6, "forward")
+            assert_close(out[1].cpu().numpy(), z[f"A/forward_layers{j}"], RT, 1e-6, "forward_layers")
+        else:
+            assert_close(out.cpu().numpy(), z[f"A/forward{j}"], RT, 2e-5, "forward")
+        np.testing.assert_array_equal(np.asarray(m.predict(Xi, Xv)).reshape(-1), z[f"A/predict{j}"].reshape(-1))
+    # a single sample may be passed 1-D (reference fm_adam.py:98)
+    p1 = m.predict(z["A/Xi1"][0].tolist(), z["A/Xv1"][0].tolist())
+    assert p1.shape == (1,) and bool(p1[0]) == bool(z["A/predict1"].reshape(-1)[0])
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("name", CLASS_NAMES)
+def test_update_embedding_and_fit_vs_reference(name, tag):
+    z, meta = load_model_fixture(name, tag)
+    sd0 = sub(z, "A/sd0")
+    m = build(name, meta, meta["B2"])
+    m.load_state_dict(sd0)
+    loss = m.update_embedding(z["A/Xi1"].tolist(), z["A/Xv1"].tolist(), z["A/Y1"].tolist())
+    assert_close(float(loss.cpu().data), z["A/loss_update_embedding"], RT, 0, "loss1")
+    sd1 = sub(z, "A/sd1")
+    assert_state_close(sd_np(m), sd1, sd0, what="sd1")
+    loss = m.update_embedding(z["A/Xi2"].tolist(), z["A/Xv2"].tolist(), z["A/Y2"].tolist())
+    assert_close(float(loss.cpu().data), z["A/loss_update_embedding2"], RT, 0, "loss2")
+    sd2 = sub(z, "A/sd2")
+    assert_state_close(sd_np(m), sd2, sd1, what="sd2")
+    m.fit(z["A/Xi2"].tolist(), z["A/Xv2"].tolist(), z["A/Y2"].tolist())
+    assert_state_close(sd_np(m), sub(z, "A/sd3"), sd2, what="sd3")
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("name", ["DeepFMOnn", "NFMOnn"])
+def test_hedge_trajectory_vs_reference(name, tag):
+    z, meta = load_model_fixture(name, tag)
+    sd0 = sub(z, "B/sd0")
+    m = build(name, meta, 1)
+    m.load_state_dict(sd0)
+    traj = [m.alpha.cpu().numpy().copy()]
+    for i in range(16):
+        m.fit([z["B/Xi"][i].tolist()], [z["B/Xv"][i].tolist()], [int(z["B/Y"][i])])
+        traj.append(m.alpha.cpu().numpy().copy())
+    assert_close(np.stack(traj), z["B/alpha_traj"], 1e-5, 1e-7, "alpha")
+    sd = sd_np(m)
+    assert_state_close(sd, sub(z, "B/sd_fit16"), sd0, what="fit16")
+    for k in sd0:
+        if "embeddings" in k or k == "bias":
+            np.testing.assert_array_equal(sd[k], sd0[k])          # ONN fit never trains the tables
+    with pytest.raises(RuntimeError):
+        m.fit(z["A/Xi1"].tolist(), z["A/Xv1"].tolist(), z["A/Y1"].tolist())   # B != batch_size, as in the reference
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("name", CLASS_NAMES)
+def test_run_experiment_vs_reference(name, tag):
+    z, meta = load_model_fixture(name, tag)
+    m = build(name, meta, 1)
+    m.load_state_dict(sub(z, "B/sd0"))
+    t, acc, roc, cm = m.run_experiment(z["B/Xi"].tolist(), z["B/Xv"].tolist(), z["B/Y"].tolist())
+    ref = meta["run_experiment"]
+    assert isinstance(t, float) and t > 0
+    assert cm == ref["confusion_matrix"]
+    assert acc == pytest.approx(ref["accuracy"], rel=1e-12)
+    assert roc["tpr"] == pytest.approx(ref["roc"]["tpr"], rel=1e-12)
+    assert roc["fpr"] == pytest.approx(ref["roc"]["fpr"], rel=1e-12)
+    sd, ref_sd = sd_np(m), sub(z, "B/sd_end")
+    tot = bad = 0
+    for k in ref_sd:
+        d = np.abs(sd[k].astype(np.float64) - ref_sd[k])
+        tot += d.size
+        bad += int((d > 1e-5 * np.maximum(np.abs(ref_sd[k]), 1e-2)).sum())
+    assert bad <= 0.002 * tot, f"{bad}/{tot} coordinates differ after 64 online steps"
+
+
+@pytest.mark.parametrize("name", ["FMAdam", "DeepFMOnn"])
+def test_pickle_and_state_dict_roundtrip(name):
+    z, meta = load_model_fixture(name, "tiny4")
+    m = build(name, meta, 1)
+    m.load_state_dict(sub(z, "B/sd0"))
+    m.fit([z["B/Xi"][0].tolist()], [z["B/Xv"][0].tolist()], [int(z["B/Y"][0])])
+    buf = io.BytesIO()
+    pickle.dump(m, buf)                                   # reference main_experiment.py:160-162
+    m2 = pickle.loads(buf.getvalue())
+    a, b = sd_np(m), sd_np(m2)
+    assert set(a) == set(b)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    Xi, Xv = z["A/Xi1"].tolist(), z["A/Xv1"].tolist()
+    o1, o2 = m.forward(Xi, Xv), m2.forward(Xi, Xv)
+    o1, o2 = (o1[0], o2[0]) if isinstance(o1, tuple) else (o1, o2)
+    np.testing.assert_array_equal(o1.cpu().numpy(), o2.cpu().numpy())
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"bias": np.float32(0)})
+    with pytest.raises(IndexError):
+        m.predict([[99] * len(meta["feature_sizes"])], [[1.0] * len(meta["feature_sizes"])])
+
+
+@pytest.mark.parametrize("rule", ["sgd", "ftrl"])
+def test_extension_rules_vs_oracle(rule):
+    """SGD and FTRL-proximal are not in the shipped reference classes (parity unpinned): checked against the oracle."""
+    z, meta = load_model_fixture("FMAdam", "criteo39s")
+    sd0 = sub(z, "A/sd0")
+    ftrl = dict(alpha=0.1, beta=1.0, l1=0.0, l2=0.001)
+    m = build("FMAdam", meta, 8, update_rule=rule, ftrl=ftrl)
+    m.load_state_dict(sd0)
+    if rule == "ftrl":      # (z, n) start reproduces the given weights
+        assert_state_close(sd_np(m), sd0, what="ftrl import")
+    Xi, Xv, Y = z["A/Xi2"], z["A/Xv2"], z["A/Y2"]
+    loss = m.update_embedding(Xi.tolist(), Xv.tolist(), Y.tolist())
+    sizes = meta["feature_sizes"]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    F = len(sizes)
+    V = np.concatenate([sd0[f"second_order_embeddings.{i}.weight"] for i in range(F)]).astype(np.float32)
+    w = np.concatenate([sd0[f"first_order_embeddings.{i}.weight"][:, 0] for i in range(F)]).astype(np.float32)
+    rows = Xi + offs[:-1][None, :]
+    if rule == "sgd":
+        st = dict(V=V.copy(), w=w.copy(), bias=np.float32(sd0["bias"]))
+        out = orc.flat_fm_step(st, rows, Xv, Y, "logits", "sgd", dict(lr=meta["n"]))
+        V1, w1, b1 = st["V"], st["w"], st["bias"]
+    else:
+        st = dict(zV=orc.ftrl_z_for_weight(V, **ftrl), nV=np.zeros_like(V), zw=orc.ftrl_z_for_weight(w, **ftrl),
+                  nw=np.zeros_like(w), zb=orc.ftrl_z_for_weight(np.float32(sd0["bias"]), **ftrl), nb=np.float32(0))
+        out = orc.flat_fm_step(st, rows, Xv, Y, "logits", "ftrl", ftrl)
+        V1 = orc.ftrl_weight(st["zV"], st["nV"], **ftrl)
+        w1 = orc.ftrl_weight(st["zw"], st["nw"], **ftrl)
+        b1 = orc.ftrl_weight(st["zb"], st["nb"], **ftrl)
+    assert_close(float(loss.cpu().data), out["loss"], RT, 0, "loss")
+    sd = sd_np(m)
+    Vh = np.concatenate([sd[f"second_order_embeddings.{i}.weight"] for i in range(F)])
+    wh = np.concatenate([sd[f"first_order_embeddings.{i}.weight"][:, 0] for i in range(F)])
+    tol = 3e-5 if rule == "ftrl" else 1e-5
+    assert_close(Vh, V1, tol, 3e-7 * np.abs(V1).max(), "V")
+    assert_close(wh, w1, tol, 3e-7 * np.abs(w1).max(), "w")
+    assert_close(sd["bias"], b1, tol, 1e-7, "bias")
