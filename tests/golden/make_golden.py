@@ -236,7 +236,46 @@ def preprocess_fixture():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def data_manager_fixture():
+    """G8: utils/data_manager.py and utils/metric_manager.py on hand-made files / arrays."""
+    from utils import data_manager, metric_manager
+    rng = np.random.default_rng(8)
+    ml = os.path.join(HERE, "handmade_movielens.tsv")
+    n_users, n_movies, n_lines = 6, 9, 30
+    with open(ml, "w") as f:
+        for i in range(n_lines):
+            f.write(f"{int(rng.integers(1, n_users + 1))}\t{int(rng.integers(1, n_movies + 1))}\t"
+                    f"{int(rng.integers(1, 6))}\t{int(880000000 + rng.integers(0, 100000))}\n")
+    fr = os.path.join(HERE, "handmade_frappe.libfm")
+    with open(fr, "w") as f:
+        for i in range(20):
+            ntok = 4                      # equal-length rows (np.asarray refuses ragged ones in numpy >= 1.24)
+            toks = [f"{int(rng.integers(0, 40))}:1" for _ in range(ntok)]
+            f.write(("1" if i % 3 else "-1") + " " + " ".join(toks) + "\n")
+    out = {}
+    X, X2, Y, Y2, dt = data_manager.load_dataset_movielens(ml, n_lines, n_users + n_movies, n_users)
+    out["ml/X"], out["ml/X2"], out["ml/Y"], out["ml/dt"] = X.toarray(), X2.toarray(), Y, dt
+    out["ml/Y2"] = np.asarray([int(v) for v in Y2])
+    # the reference hands numpy float32 stamps to datetime.utcfromtimestamp, which Python 3.10 rejects: feed floats
+    sX, sY, order = data_manager.sort_dataset_movielens(X, Y2, [float(t) for t in dt])
+    out["ml/sorted_X"], out["ml/sorted_Y"] = sX.toarray(), sY
+    fx, fy = data_manager.load_dataset_fappe(fr)
+    out["frappe/X"], out["frappe/Y"] = fx, fy
+    pred, real = rng.normal(size=50), rng.normal(size=50)
+    out["metric/pred"], out["metric/real"] = pred, real
+    out["metric/reg"] = metric_manager.regression_metric(pred, real)
+    sp, sr = np.sign(pred), np.sign(real)
+    m, acc = metric_manager.classfication_metric(sp, sr)
+    out["metric/cls"], out["metric/cls_acc"] = m, acc
+    path = os.path.join(HERE, "data_manager.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
+    if "--only-data-manager" in sys.argv:
+        data_manager_fixture()
+        return
     assert any(p.rstrip("/") == "/root/reference" for p in sys.path), "run with PYTHONPATH=/root/reference"
     rng = np.random.default_rng(39)
     criteo39s = [int(s) for s in rng.integers(3, 24, size=39)]      # 39 fields, small vocabularies
@@ -245,6 +284,7 @@ def main():
         model_fixture(name, "tiny4", [7, 5, 11, 3], k=4, L=2, H=32, n=0.01, seed=200 + 10 * i)
     fm_ftrl_fixture()
     preprocess_fixture()
+    data_manager_fixture()
 
 
 if __name__ == "__main__":

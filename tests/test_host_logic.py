@@ -1,0 +1,191 @@
+"""CPU-only tests of the host side: input readers / batchers against the golden fixture, input normalisation,
+flat-table geometry, and that libfmx.so loads and exports every symbol of include/fmx.h (no compute calls)."""
+import json
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    with open(os.path.join(golden_dir, "data_preprocess.json")) as fh:
+        return json.load(fh)
+
+
+def _paths(golden_dir):
+    return (os.path.join(golden_dir, "handmade_train_input.csv"), os.path.join(golden_dir, "handmade_category_emb.csv"),
+            os.path.join(golden_dir, "handmade.libsvm"))
+
+
+def test_read_criteo_data(gold, golden_dir):
+    from utils import data_preprocess as dp
+    csv, emb, _ = _paths(golden_dir)
+    r = dp.read_criteo_data(csv, emb)
+    g = gold["read_criteo_data"]
+    assert r["size"] == g["size"] and r["label"] == g["label"] and r["index"] == g["index"]
+    assert r["value"] == g["value"] and r["feature_sizes"] == g["feature_sizes"]
+
+
+def test_batchers_consume_random_like_the_reference(gold, golden_dir):
+    from utils import data_preprocess as dp
+    csv, emb, _ = _paths(golden_dir)
+    random.seed(11)
+    a = dp.create_ten_iter(csv, emb, 4, 8)
+    g = gold["create_ten_iter"]
+    assert a[0] == g["Xi"] and a[1] == g["Xv"] and a[2] == g["Y"] and [list(t) for t in a[3]] == g["ratio"]
+    random.seed(12)
+    a = dp.create_dataset(csv, emb, 3, 4, 8)
+    g = gold["create_dataset"]
+    assert a[0] == g["Xi"] and a[1] == g["Xv"] and a[2] == g["Y"] and [list(t) for t in a[3]] == g["ratio"]
+    random.seed(13)
+    r = dp.balance_criteo_data(csv, emb)
+    g = gold["balance_criteo_data"]
+    assert r["size"] == g["size"] and r["label"] == g["label"] and r["index"] == g["index"] and r["value"] == g["value"]
+
+
+def test_read_svm_file(gold, golden_dir):
+    from utils import data_preprocess as dp
+    _, _, svm = _paths(golden_dir)
+    r = dp.read_svm_file(svm)
+    g = gold["read_svm_file"]
+    assert int(r["size"]) == g["size"]
+    np.testing.assert_array_equal(r["label"], g["label"])
+    np.testing.assert_array_equal(r["index"], g["index"])
+    np.testing.assert_array_equal(r["value"], g["value"])
+    np.testing.assert_array_equal(r["feature_sizes"], g["feature_sizes"])
+    assert r["index"].dtype.kind == "i" and r["label"].dtype.kind == "i"
+    random.seed(14)
+    r = dp.balance_svm_data(svm)
+    g = gold["balance_svm_data"]
+    assert int(r["size"]) == g["size"]
+    np.testing.assert_array_equal(r["label"], g["label"])
+    np.testing.assert_array_equal(r["index"], g["index"])
+    np.testing.assert_array_equal(r["value"], g["value"])
+
+
+def test_normalize_inputs():
+    import fmx
+    sizes = [7, 5, 11, 3]
+    idx, xv = fmx.normalize_inputs([1, 2, 3, 0], [1, 1, 1, 1], 4, sizes)          # a 1-D single sample
+    assert idx.shape == (1, 4) and idx.dtype == np.int32 and xv is None
+    idx, xv = fmx.normalize_inputs([[1, 2, 3, 0], [6, 4, 10, 2]], [[1, .5, 1, 1], [1, 1, 1, 1]], 4, sizes)
+    assert idx.shape == (2, 4) and xv.dtype == np.float32 and xv[0, 1] == 0.5
+    for bad in ([[7, 0, 0, 0]], [[-1, 0, 0, 0]], [[0, 0, 0, 3]]):
+        with pytest.raises(IndexError):
+            fmx.normalize_inputs(bad, [[1, 1, 1, 1]], 4, sizes)
+    with pytest.raises(ValueError):
+        fmx.normalize_inputs([[1, 2, 3]], [[1, 1, 1, 1]], 4, sizes)
+
+
+def test_flat_table_geometry():
+    import fmx
+    assert [fmx.padded_k(k) for k in (1, 4, 5, 10, 16, 17, 64)] == [4, 4, 8, 16, 16, 32, 64]
+    with pytest.raises(ValueError):
+        fmx.padded_k(65)
+    t = fmx.FlatTable([7, 5, 11, 3], 10, device="cpu")
+    assert (t.kp, t.row_stride, t.n_rows) == (16, 32, 26)
+    np.testing.assert_array_equal(t.offsets_host, [0, 7, 12, 23, 26])
+    t2 = fmx.FlatTable([7, 5, 11, 3], 16, layout="ftrl", device="cpu")
+    assert t2.row_stride == 48 and t2.bias.numel() == 2
+    with pytest.raises(ValueError):
+        fmx.FlatTable([7, 0], 4, device="cpu")
+    with pytest.raises(ValueError):
+        fmx.FlatTable([7, 5], 16, device="cpu", row_stride=18)
+    # reference-shaped import / export round trip on the flat buffer
+    import torch
+    first = [torch.randn(s, 1) for s in (7, 5, 11, 3)]
+    second = [torch.randn(s, 10) for s in (7, 5, 11, 3)]
+    t.load_reference(first, second)
+    f2, s2 = t.export_reference()
+    for a, b in zip(first + second, f2 + s2):
+        assert torch.equal(a, b)
+    assert float(t.rows[:, 10:16].abs().sum()) == 0 and float(t.rows[:, 17:].abs().sum()) == 0
+
+
+def test_library_exports_every_declared_symbol():
+    import fmx
+    lib = fmx._lib.load()
+    header = open(os.path.join(ROOT, "include", "fmx.h")).read()
+    declared = set(re.findall(r"\b(fmx_[a-z_]+)\s*\(", header))
+    assert declared == set(fmx._lib.EXPORTS), declared ^ set(fmx._lib.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.fmx_version() == 100
+    assert (lib.fmx_sorted_width(1), lib.fmx_sorted_width(65), lib.fmx_sorted_width(4096)) == (64, 128, 4096)
+    assert (lib.fmx_sorted_bbits(1), lib.fmx_sorted_bbits(4096), lib.fmx_sorted_bbits(4097)) == (6, 12, 13)
+
+
+def test_models_fail_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from models.models_online_deep.fm_adam import FMAdam
+    with pytest.raises(RuntimeError, match="gfx950"):
+        FMAdam([3, 4], embedding_size=4)
+    import fmx
+    with pytest.raises(RuntimeError, match="ROCm GPU"):
+        fmx.FMEngine(fmx.FlatTable([3, 4], 4, device="cpu"))
+
+
+@pytest.mark.parametrize("task", ["cls", "reg"])
+def test_fm_ftrl_class_vs_reference(task, golden_dir, capsys):
+    """Hot path B (fp64, host): same seed => same init draws => same predictions and final weights as the reference."""
+    import torch
+    from models.models_online.FM_FTRL import FM_FTRL
+    z = np.load(os.path.join(golden_dir, "FM_FTRL.npz"))
+    torch.manual_seed(5)
+    m = FM_FTRL(torch.DoubleTensor(z[f"{task}/X"]), torch.DoubleTensor(z[f"{task}/y"]), task, float(z[f"{task}/eta"]),
+                int(z[f"{task}/m"]))
+    pred, real, secs = m.online_learning()
+    out = capsys.readouterr().out
+    assert out.startswith("FM_FTRL_0.005_8_start\n 0 th : pred ") and "learning time : " in out
+    assert pred.shape == ((256, 1) if task == "cls" else (256, 1, 1)) and real.shape == (256,)
+    assert isinstance(secs, float) and m.model_name == "FM_FTRL" and m.eta == 0.005 and m.m == 8
+    np.testing.assert_allclose(pred.reshape(-1), z[f"{task}/pred"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_array_equal(real, z[f"{task}/real"])
+    np.testing.assert_allclose(m.w1.numpy(), z[f"{task}/w1"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(m.W2.numpy(), z[f"{task}/W2"], rtol=1e-10, atol=1e-13)
+    assert m.w1.dtype == torch.float64 and tuple(m.W2.shape) == (16, 7)
+
+
+def test_fm_ftrl_errors():
+    import torch
+    from models.models_online.FM_FTRL import FM_FTRL
+    X = torch.DoubleTensor(np.full((3, 8), np.nan))
+    with pytest.raises(ValueError, match="Nan contained"):
+        FM_FTRL(X, torch.DoubleTensor([1, -1, 1]), "cls", 0.1, 2).online_learning()
+    with pytest.raises(NotImplementedError):
+        FM_FTRL(torch.DoubleTensor(np.ones((3, 8))), torch.DoubleTensor([1, -1, 1]), "rank", 0.1, 2).online_learning()
+
+
+def test_data_manager_and_metrics_vs_reference(golden_dir, tmp_path):
+    from utils import data_manager as dm
+    from utils import metric_manager as mm
+    z = np.load(os.path.join(golden_dir, "data_manager.npz"))
+    X, X2, Y, Y2, dt = dm.load_dataset_movielens(os.path.join(golden_dir, "handmade_movielens.tsv"), 30, 15, 6)
+    np.testing.assert_array_equal(X.toarray(), z["ml/X"])
+    np.testing.assert_array_equal(X2.toarray(), z["ml/X2"])
+    assert X.dtype == np.float32 and X2.dtype == np.float64 and dt.dtype == np.float32
+    np.testing.assert_array_equal(Y, z["ml/Y"])
+    np.testing.assert_array_equal([int(v) for v in Y2], z["ml/Y2"])
+    np.testing.assert_array_equal(dt, z["ml/dt"])
+    sX, sY, _ = dm.sort_dataset_movielens(X, Y2, dt)
+    np.testing.assert_array_equal(sX.toarray(), z["ml/sorted_X"])
+    np.testing.assert_array_equal(sY, z["ml/sorted_Y"])
+    fx, fy = dm.load_dataset_fappe(os.path.join(golden_dir, "handmade_frappe.libfm"))
+    np.testing.assert_array_equal(fx, z["frappe/X"])
+    np.testing.assert_array_equal(fy, z["frappe/Y"])
+    ragged = tmp_path / "ragged.libfm"
+    ragged.write_text("1 3:1 4:1 5:1\n-1 3:1\n1 9:1 4:1\n")
+    rx, ry = dm.load_dataset_fappe(str(ragged))
+    assert [list(r) for r in rx] == [[0], [3, 1], [0, 1, 2]] and list(ry) == [-1.0, 1.0, 1.0]
+    np.testing.assert_allclose(mm.regression_metric(z["metric/pred"], z["metric/real"]), z["metric/reg"], rtol=1e-12)
+    sp, sr = np.sign(z["metric/pred"]), np.sign(z["metric/real"])
+    m, acc = mm.classfication_metric(sp, sr)
+    np.testing.assert_allclose(m, z["metric/cls"], rtol=1e-12)
+    np.testing.assert_allclose(acc, z["metric/cls_acc"], rtol=1e-12)

@@ -59,7 +59,9 @@ def test_forward_pieces_vs_reference(name, tag):
         Xi, Xv = z[f"A/Xi{j}"].tolist(), z[f"A/Xv{j}"].tolist()
         if name != "FMAdam":
             assert_close(m.first_order(Xi, Xv).cpu().numpy(), z[f"A/first_order{j}"], RT, 1e-7, "first_order")
-            assert_close(m.second_order(Xi, Xv).cpu().numpy(), z[f"A/second_order{j}"], RT, 4e-6, "second_order")
+            # bi = 0.5 (S^2 - sum e^2) cancels: fp32 leaves ~1e-6 of max|bi| whatever the summation order
+            so = z[f"A/second_order{j}"]
+            assert_close(m.second_order(Xi, Xv).cpu().numpy(), so, RT, 1e-6 * np.abs(so).max(), "second_order")
             assert_close(m.forward_fm(Xi, Xv).cpu().numpy(), z[f"A/forward_fm{j}"], RT, 2e-5, "forward_fm")
         out = m.forward(Xi, Xv)
         if isinstance(out, tuple):
