@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05) indices instead of uniform (secondary workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--row-stride", type=int, default=0)
+    ap.add_argument("--rule", default="ftrl", choices=["ftrl", "sgd", "signadam"],
+                    help="update rule (the headline metric is ftrl; the others are for kernel comparisons)")
     args = ap.parse_args()
 
     import torch
@@ -97,12 +99,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- resident state: FTRL table (z, n) with V ~ N(0, 0.01) folded into z, first-order weights 0 ----
-    table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="ftrl", device=dev,
-                          row_stride=args.row_stride if args.row_stride else None)
+    RULE = args.rule
+    table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="ftrl" if RULE == "ftrl" else "weights", device=dev,
+                          row_stride=args.row_stride if args.row_stride else None, ftrl=HYPER)
     g = torch.Generator(device=dev).manual_seed(SEED)
     w0 = torch.randn((table.n_rows, K_EMB), generator=g, device=dev) * 0.01
-    d0 = HYPER["beta"] / HYPER["alpha"] + HYPER["l2"]
-    table.rows[:, :K_EMB] = -w0 * d0 - torch.sign(w0) * HYPER["l1"]
+    table.rows[:, :K_EMB] = w0
+    if RULE == "ftrl":          # n = 0 and the z that reproduces V (first-order weights and bias start at 0)
+        zo = table.z_offset
+        table.rows[:, zo:zo + K_EMB] = fmx.table.ftrl_z_for_weight_torch(w0, table.ftrl)
     del w0
     hyper = fmx.Hyper(**HYPER)
     eng = fmx.FMEngine(table, max_batch=BATCH)
@@ -117,10 +122,10 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warm-up, then EXACTLY K timed steps ----
-    eng.stream(hyper, "ftrl", "logits", idx_pool, y_pool, args.warmup, loss_buf)
+    eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.warmup, loss_buf)
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = eng.stream(hyper, "ftrl", "logits", idx_pool, y_pool, args.steps, loss_buf, timed=True)
+    kernel_ms = eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.steps, loss_buf, timed=True)
     barrier()
     dt = time.perf_counter() - t0
     eng.check_error_flag()
@@ -130,7 +135,7 @@ def main():
     # the same K steps without per-launch events (informational: what the event bracketing costs)
     barrier()
     t1 = time.perf_counter()
-    eng.stream(hyper, "ftrl", "logits", idx_pool, y_pool, args.steps, loss_buf, timed=False)
+    eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.steps, loss_buf, timed=False)
     barrier()
     dt_noev = time.perf_counter() - t1
 
@@ -161,7 +166,7 @@ def main():
     stream_gbps = 5 * probe.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del probe
 
-    sort_ms, fwd_ms, upd_ms = [v / args.steps for v in kernel_ms]
+    sort_ms, fwd_ms, upd_ms, fix_ms = [v / args.steps for v in kernel_ms]
     samples = args.steps * BATCH * world
     value = samples / dt
     ach = BYTES_K_UPDATE * BATCH / (upd_ms * 1e-3) / 1e9
@@ -185,7 +190,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_fm_update", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": BYTES_K_UPDATE * BATCH, "avg_launch_ms": upd_ms},
-        "kernels_ms_per_step": {"k_sort_occ": sort_ms, "k_fm_forward": fwd_ms, "k_fm_update": upd_ms},
+        "kernels_ms_per_step": {"k_sort_occ": sort_ms, "k_fm_forward": fwd_ms, "k_fm_update": upd_ms,
+                                "k_fm_fixup": fix_ms},
         "step_algorithmic": {"bytes_per_sample": BYTES_STEP_FTRL, "GBps": value / world * BYTES_STEP_FTRL / 1e9,
                              "frac_of_peak": value / world * BYTES_STEP_FTRL / 1e9 / HBM_PEAK_GBPS,
                              "frac_of_measured_stream_read": value / world * BYTES_STEP_FTRL / 1e9 / stream_gbps},

@@ -1,17 +1,22 @@
 // fmx_kernels.hip -- gfx950 (MI355X, CDNA4) kernels for the FM / DeepFM / NFM online hot path and their C ABI.
 //
-// Three kernels make one mini-batch step (DESIGN.md has the data layout and the byte accounting):
+// Four kernels make one mini-batch step (DESIGN.md has the data layout and the byte accounting):
 //
 //   k_sort_occ    one workgroup per field: the batch's (local index, sample) pairs are packed into 32-bit
-//                 composites and bitonic-sorted in LDS.  Equal rows become adjacent runs ordered by sample, so
-//                 the duplicate-row reduction the reference gets from embedding_dense_backward
-//                 (reference fm_adam.py:67) is deterministic.  Independent of the weights.
+//                 composites and bitonic-sorted (registers + wave shuffles, LDS only for the cross-wave stages).
+//                 Equal rows become adjacent runs ordered by sample, so the duplicate-row reduction the reference
+//                 gets from embedding_dense_backward (reference fm_adam.py:67) is deterministic.  Independent of
+//                 the weights.
 //   k_fm_forward  one 64-lane wavefront per sample, LPR lanes per gathered row (16-byte loads, one request per
-//                 64-byte row), butterfly shuffles for the field sums  (reference fm_adam.py:35-53), fused
-//                 loss / dlogit epilogue (fm_adam.py:61,66 / :76,80).
-//   k_fm_update   one wavefront per 64 sorted occurrences: a segmented scan over the run of every unique row,
-//                 then ONE fused read-modify-write of that row under the chosen rule
-//                 (reference loss.backward() + optimizer.step(), fm_adam.py:67-68 / :81-82).
+//                 64-byte row), every index / row load of the sample issued before the first use, butterfly
+//                 shuffles for the field sums (reference fm_adam.py:35-53), fused loss / dlogit epilogue
+//                 (fm_adam.py:61,66 / :76,80).
+//   k_fm_update   one wavefront per tile of 64 sorted occurrences: a segmented scan over the runs in the tile; a run
+//                 that lies inside the tile gets ONE fused read-modify-write of its row under the chosen rule
+//                 (reference loss.backward() + optimizer.step(), fm_adam.py:67-68 / :81-82); a run that crosses a tile
+//                 boundary leaves a partial sum.  The last workgroup reduces the bias gradient and the loss.
+//   k_fm_fixup    one wavefront per run that crosses tile boundaries (rows hit > 64 times, i.e. the small-vocabulary
+//                 fields): adds the partial sums in tile order and applies the row update.
 //
 // Everything is HBM / cache-line bound integer+fp32 work; there is no GEMM here and no MFMA.
 
@@ -70,10 +75,16 @@ __device__ __forceinline__ float4 shfl4(float4 v, int src) {
   return {__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src), __shfl(v.w, src)};
 }
 
-// FTRL-proximal weight from (z, n)  (McMahan et al. 2013, Algorithm 1)
+// v_rcp_f32 / v_sqrt_f32 are 1-ulp instructions; the IEEE-exact expansions hipcc emits for `/` and sqrtf cost 10-14
+// VALU instructions each and made the FTRL kernels VALU-bound (profiles/r01_*).  1 ulp is ~1e-7 relative, two orders
+// below the 1e-5 parity tolerance.
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// FTRL-proximal weight from (z, n)  (McMahan et al. 2013, Algorithm 1); h.alpha holds 1/alpha on the device
 __device__ __forceinline__ float ftrl_w(float z, float n, const fmx_hyper_t &h) {
-  const float denom = (h.beta + sqrtf(n)) / h.alpha + h.l2;
-  const float w = -(z - copysignf(h.l1, z)) / denom;
+  const float denom = (h.beta + sqrt_(n)) * h.alpha + h.l2;
+  const float w = -(z - copysignf(h.l1, z)) * rcp_(denom);
   return fabsf(z) <= h.l1 ? 0.f : w;
 }
 __device__ __forceinline__ float4 ftrl_w4(float4 z, float4 n, const fmx_hyper_t &h) {
@@ -82,14 +93,14 @@ __device__ __forceinline__ float4 ftrl_w4(float4 z, float4 n, const fmx_hyper_t 
 // one FTRL-proximal update of (z, n) by gradient g; w is the weight derived from the OLD (z, n)
 __device__ __forceinline__ void ftrl_upd(float &z, float &n, float w, float g, const fmx_hyper_t &h) {
   const float n2 = n + g * g;
-  const float sigma = (sqrtf(n2) - sqrtf(n)) / h.alpha;
+  const float sigma = (sqrt_(n2) - sqrt_(n)) * h.alpha;
   z = z + g - sigma * w;
   n = n2;
 }
 
 template <int RULE>
 __device__ __forceinline__ float apply_rule(float p, float g, const fmx_hyper_t &h) {
-  if (RULE == FMX_RULE_SIGNADAM) return p - h.lr * g / (fabsf(g) + h.eps);
+  if (RULE == FMX_RULE_SIGNADAM) return p - h.lr * g * rcp_(fabsf(g) + h.eps);
   return p - h.lr * g;  // FMX_RULE_SGD
 }
 template <int RULE>
@@ -115,36 +126,88 @@ struct SortArgs {
   int32_t B, F, Bp, bbits;
 };
 
+// Bitonic network on N = Bp composites held E per thread in a blocked layout (element i = tid * E + r):
+//   partner distance j <  E        in-thread compare-exchange
+//   E <= j < 64 E                  partner in another lane of the wave: __shfl_xor
+//   j >= 64 E                      partner in another wave: through LDS
+template <int E>
+__device__ __forceinline__ void bitonic_local(uint32_t (&v)[E], int tid, int k, int jmax) {
+  // stages j = jmax, jmax/2, ..., 1 of merge level k, all of which stay inside one wave
+  const int i0 = tid * E;
+  const int lane = tid & 63;
+#pragma unroll 1
+  for (int j = jmax; j >= E && j > 0; j >>= 1) {
+    const int lj = j / E;  // lane distance
+    const bool lower = (lane & lj) == 0;
+    const bool up = (i0 & k) == 0;  // (i & k) is the same for all r because k > j >= E
+    const bool take_min = lower == up;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const uint32_t o = __shfl_xor(v[r], lj);
+      v[r] = take_min ? (v[r] < o ? v[r] : o) : (v[r] > o ? v[r] : o);
+    }
+  }
+#pragma unroll
+  for (int j = E / 2; j > 0; j >>= 1) {
+    if (j <= jmax) {
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        if ((r & j) == 0) {
+          const bool up = ((i0 + r) & k) == 0;
+          const uint32_t x = v[r], y = v[r + j];
+          if ((x > y) == up) { v[r] = y; v[r + j] = x; }
+        }
+      }
+    }
+  }
+}
+
+template <int E>
 __global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
   extern __shared__ uint32_t sm[];
   const int f = blockIdx.x;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x;  // nt * E == Bp
   const uint32_t vocab = (uint32_t)(a.foff[f + 1] - a.foff[f]);
-  for (int i = tid; i < a.Bp; i += nt) {
+  uint32_t v[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = tid * E + r;
     uint32_t c = SENT;
     if (i < a.B) {
       const uint32_t li = (uint32_t)a.idx[(size_t)i * a.F + f];
       if (li < vocab) c = (li << a.bbits) | (uint32_t)i;
       else if (a.error) *a.error = 1;
     }
-    sm[i] = c;
+    v[r] = c;
   }
-  __syncthreads();
+  const int wave_span = 64 * E;  // elements held by one wave
   const int half = a.Bp >> 1;
   for (int k = 2; k <= a.Bp; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < half; t += nt) {
-        const int i = 2 * t - (t & (j - 1));
-        const int l = i + j;
-        const uint32_t x = sm[i], y = sm[l];
-        const bool up = (i & k) == 0;
-        if ((x > y) == up) { sm[i] = y; sm[l] = x; }
+    int j = k >> 1;
+    if (j >= wave_span) {
+      // cross-wave stages through LDS
+#pragma unroll
+      for (int r = 0; r < E; ++r) sm[tid * E + r] = v[r];
+      __syncthreads();
+      for (; j >= wave_span; j >>= 1) {
+        for (int t = tid; t < half; t += nt) {
+          const int i = 2 * t - (t & (j - 1));
+          const int l = i + j;
+          const uint32_t x = sm[i], y = sm[l];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { sm[i] = y; sm[l] = x; }
+        }
+        __syncthreads();
       }
+#pragma unroll
+      for (int r = 0; r < E; ++r) v[r] = sm[tid * E + r];
       __syncthreads();
     }
+    bitonic_local<E>(v, tid, k, j);
   }
-  uint32_t *dst = a.sorted + (size_t)f * a.Bp;
-  for (int i = tid; i < a.Bp; i += nt) dst[i] = sm[i];
+  uint32_t *dst = a.sorted + (size_t)f * a.Bp + (size_t)tid * E;
+#pragma unroll
+  for (int r = 0; r < E; ++r) dst[r] = v[r];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -159,13 +222,16 @@ struct FwdArgs {
   const float *y;
   fmx_fwd_out_t out;
   fmx_hyper_t h;
-  int32_t B, F, kp, stride, loss_kind;
+  int32_t B, F, kp, stride, zoff, loss_kind;
   float inv_b;
 };
 
-template <int LPR, int LAYOUT>
+// NPASS > 0: the field loop is fully unrolled (F <= NPASS * SLOTS) and every index, value, offset and row load of the
+// sample is issued before the first use, so one wave keeps up to 3 * NPASS row requests in flight.  NPASS == 0: generic.
+template <int LPR, int LAYOUT, int NPASS>
 __global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
   constexpr int SLOTS = WAVE / LPR;
+  constexpr int NP = NPASS > 0 ? NPASS : 1;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.B) return;  // wave-uniform
@@ -175,40 +241,57 @@ __global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
   float4 s = splat(0.f), ss = splat(0.f);
   float fo = 0.f;
   bool bad = false;
-#pragma unroll 4
-  for (int f0 = 0; f0 < a.F; f0 += SLOTS) {
-    const int f = f0 + slot;
-    if (f < a.F) {
-      const size_t o = (size_t)b * a.F + f;
-      const uint32_t li = (uint32_t)a.idx[o];
-      const float x = a.xv ? a.xv[o] : 1.f;
-      const int64_t lo = a.foff[f], hi = a.foff[f + 1];
-      float f1 = 0.f;
-      if (li < (uint32_t)(hi - lo)) {
-        const float *rp = a.rows + (size_t)(lo + li) * a.stride;
-        float4 v;
-        float w1 = 0.f;
-        if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
-          v = *reinterpret_cast<const float4 *>(rp + 4 * q);
-          if (q == 0) w1 = rp[kp];
-        } else {
-          const float4 z4 = *reinterpret_cast<const float4 *>(rp + 4 * q);
-          const float4 n4 = *reinterpret_cast<const float4 *>(rp + kp + 4 * q);
-          v = ftrl_w4(z4, n4, a.h);
-          if (q == 0) {
-            const float2 zn = *reinterpret_cast<const float2 *>(rp + 2 * kp);
-            w1 = ftrl_w(zn.x, zn.y, a.h);
-          }
-        }
-        const float4 e = x * v;
-        s = s + e;
-        ss = ss + e * e;
-        f1 = w1 * x;
-        fo += f1;
-      } else {
-        bad = true;
+  const int n_outer = NPASS > 0 ? 1 : (a.F + SLOTS - 1) / SLOTS;
+  for (int it = 0; it < n_outer; ++it) {
+    uint32_t li[NP];
+    float x[NP];
+    int64_t lo[NP];
+    uint32_t vocab[NP];
+    bool live[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int f = (it * NP + p) * SLOTS + slot;
+      live[p] = f < a.F;
+      li[p] = 0;
+      x[p] = 1.f;
+      lo[p] = 0;
+      vocab[p] = 0;
+      if (live[p]) {
+        const size_t o = (size_t)b * a.F + f;
+        li[p] = (uint32_t)a.idx[o];
+        if (a.xv) x[p] = a.xv[o];
+        lo[p] = a.foff[f];
+        vocab[p] = (uint32_t)(a.foff[f + 1] - lo[p]);
       }
-      if (a.out.first && q == 0) a.out.first[o] = f1;
+    }
+    // both layouts keep [ V | w ] at the head of the row: the forward never touches the FTRL (z, n) half
+    float4 r0[NP];
+    float rw[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      r0[p] = splat(0.f);
+      rw[p] = 0.f;
+      if (live[p] && li[p] < vocab[p]) {
+        const float *rp = a.rows + (size_t)(lo[p] + li[p]) * a.stride;
+        r0[p] = *reinterpret_cast<const float4 *>(rp + 4 * q);
+        if (q == 0) rw[p] = rp[kp];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (live[p]) {
+        float f1 = 0.f;
+        if (li[p] < vocab[p]) {
+          const float4 e = x[p] * r0[p];
+          s = s + e;
+          ss = ss + e * e;
+          f1 = rw[p] * x[p];
+          fo += f1;
+        } else {
+          bad = true;
+        }
+        if (a.out.first && q == 0) a.out.first[(size_t)b * a.F + (it * NP + p) * SLOTS + slot] = f1;
+      }
     }
   }
   if (bad && a.out.error) *a.out.error = 1;
@@ -264,6 +347,8 @@ struct UpdArgs {
   const int64_t *foff;
   float *bias;
   const uint32_t *sorted;
+  float *parts;   // [F * tiles, 2 (lead, trail), REC] partial sums of runs that cross a tile boundary
+  int32_t *meta;  // [F * tiles, 2] (lead_state, trail_state)
   const float *xv;
   const float *S;
   const float *dz_first;
@@ -272,9 +357,12 @@ struct UpdArgs {
   const float *loss_b;
   float *loss_out;
   fmx_hyper_t h;
-  int32_t B, F, Bp, bbits, kp, stride;
+  int32_t B, F, Bp, bbits, kp, stride, zoff;
   float inv_b;
 };
+
+// tile meta states
+constexpr int LEAD_NONE = 0, LEAD_CLOSES = 1, LEAD_THROUGH = 2;
 
 // deterministic block reduction of src[0..n) by 256 threads (strided partials, then an LDS tree)
 __device__ float block_sum_256(const float *src, int n, float *sm) {
@@ -311,12 +399,73 @@ __device__ void bias_and_loss(const UpdArgs &a) {
   }
 }
 
+// The state of one row as LPR lanes hold it: lane q owns coordinates 4q..4q+3; lane 0 also the first-order part.
+//   WEIGHTS row  [ V(kp) | w | pad ]
+//   FTRL row     [ V(kp) | w, zw, nw, pad | ... | zV(kp) | nV(kp) ]   zV starts at float `zoff`;
+//                V and w are the weights derived from (z, n), re-derived and stored by every update
+struct RowRegs {
+  float4 v;       // V
+  float4 z, n;    // FTRL only
+  float4 fo;      // lane 0: (w, zw, nw, -)
+};
+
+template <int LAYOUT>
+__device__ __forceinline__ RowRegs load_row(const float *rp, int q, int kp, int zoff) {
+  RowRegs r;
+  r.v = *reinterpret_cast<const float4 *>(rp + 4 * q);
+  r.z = splat(0.f);
+  r.n = splat(0.f);
+  r.fo = splat(0.f);
+  if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
+    if (q == 0) r.fo.x = rp[kp];
+  } else {
+    r.z = *reinterpret_cast<const float4 *>(rp + zoff + 4 * q);
+    r.n = *reinterpret_cast<const float4 *>(rp + zoff + kp + 4 * q);
+    if (q == 0) r.fo = *reinterpret_cast<const float4 *>(rp + kp);
+  }
+  return r;
+}
+
+// gradient of the row from the run sums (dV = cV - V * cA, dw = cw), one application of the rule, store
+template <int LAYOUT, int RULE>
+__device__ __forceinline__ void update_row(float *rp, int q, int kp, int zoff, RowRegs r, float4 cV, float4 cA, float cw,
+                                           const fmx_hyper_t &h) {
+  const float4 gr = cV - r.v * cA;
+  if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
+    *reinterpret_cast<float4 *>(rp + 4 * q) = apply_rule4<RULE>(r.v, gr, h);
+    if (q == 0) rp[kp] = apply_rule<RULE>(r.fo.x, cw, h);
+  } else {
+    float4 z4 = r.z, n4 = r.n;
+    ftrl_upd(z4.x, n4.x, r.v.x, gr.x, h);
+    ftrl_upd(z4.y, n4.y, r.v.y, gr.y, h);
+    ftrl_upd(z4.z, n4.z, r.v.z, gr.z, h);
+    ftrl_upd(z4.w, n4.w, r.v.w, gr.w, h);
+    *reinterpret_cast<float4 *>(rp + zoff + 4 * q) = z4;
+    *reinterpret_cast<float4 *>(rp + zoff + kp + 4 * q) = n4;
+    *reinterpret_cast<float4 *>(rp + 4 * q) = ftrl_w4(z4, n4, h);
+    if (q == 0) {
+      float4 fo = r.fo;
+      ftrl_upd(fo.y, fo.z, fo.x, cw, h);
+      fo.x = ftrl_w(fo.y, fo.z, h);
+      *reinterpret_cast<float4 *>(rp + kp) = fo;
+    }
+  }
+}
+
+// partial-sum record: [cV (kp) | cA (kp) | cw, pad3]
+__device__ __forceinline__ void store_part(float *rec, int q, int kp, float4 cV, float4 cA, float cw) {
+  *reinterpret_cast<float4 *>(rec + 4 * q) = cV;
+  *reinterpret_cast<float4 *>(rec + kp + 4 * q) = cA;
+  if (q == 0) rec[2 * kp] = cw;
+}
+
 template <int LPR, int LAYOUT, int RULE, bool HAS_GBI>
 __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   constexpr int SLOTS = WAVE / LPR;  // occurrences handled per pass
-  constexpr int PASSES = LPR;        // passes per 64-entry window
+  constexpr int PASSES = LPR;        // passes per 64-entry tile
   constexpr int GROUP = PASSES < 4 ? PASSES : 4;  // passes whose loads are issued together
   constexpr int LAST = (SLOTS - 1) * LPR;          // first lane of the last slot
+  constexpr int REC = 2 * LPR * 4 + 4;
   if (blockIdx.x == gridDim.x - 1) {  // the last block owns the bias and the loss reduction
     bias_and_loss<LAYOUT, RULE>(a);
     return;
@@ -328,35 +477,33 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   const int gt = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gt >= a.F * tiles_per_field) return;
   const int f = gt / tiles_per_field;
-  int base = (gt - f * tiles_per_field) << 6;
+  const int base = (gt - f * tiles_per_field) << 6;
   const uint32_t *sf = a.sorted + (size_t)f * a.Bp;
   const int bbits = a.bbits;
   const uint32_t bmask = (1u << bbits) - 1u;
   const uint32_t NOKEY = SENT >> bbits;
 
-  uint32_t c = sf[base + lane];
-  const uint32_t prevkey = base == 0 ? NOKEY : (sf[base - 1] >> bbits);
-  // entries of a run whose head lies in an earlier tile belong to that tile's wave (it runs ahead)
-  const bool own = (c != SENT) && ((c >> bbits) != prevkey);
-  if (__ballot(own) == 0ull) return;
+  const uint32_t c = sf[base + lane];
+  const uint32_t prevkey = (base == 0 ? SENT : sf[base - 1]) >> bbits;
+  const uint32_t nextc = (base + 64 < a.Bp) ? sf[base + 64] : SENT;
   const size_t row0 = (size_t)a.foff[f];
+  float *part = a.parts + (size_t)gt * 2 * REC;
 
-  bool first_window = true;
+  int lead_state = LEAD_NONE, trail_state = 0;
   bool carry_open = false;
   uint32_t carry_key = NOKEY;
   float4 carV = splat(0.f), carA = splat(0.f);
   float carw = 0.f;
 
-  while (true) {
-    const uint32_t nextc = (base + 64 < a.Bp) ? sf[base + 64] : SENT;
-    const uint32_t ck0 = carry_key;
+  if (__ballot(c != SENT) != 0ull) {
 #pragma unroll
     for (int p0 = 0; p0 < PASSES; p0 += GROUP) {
       uint32_t ks[GROUP], kn[GROUP];
-      bool val[GROUP];
+      bool val[GROUP], tail[GROUP], upd[GROUP];
       float4 cV[GROUP], cA[GROUP];
       float cw[GROUP];
-      // ---- issue the loads of GROUP passes ----
+      RowRegs row[GROUP];
+      // ---- issue every load of GROUP passes: run sums need S (L2), complete runs need their row (HBM / MALL) ----
 #pragma unroll
       for (int g = 0; g < GROUP; ++g) {
         const int e = (p0 + g) * SLOTS + slot;
@@ -365,11 +512,17 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
         const uint32_t cn = (e + 1 < 64) ? cnx : nextc;
         ks[g] = cs >> bbits;
         kn[g] = cn >> bbits;
-        const bool ownv = __shfl((int)own, e) != 0;
-        val[g] = first_window ? ownv : (cs != SENT && ks[g] == ck0);
+        val[g] = cs != SENT;
+        tail[g] = val[g] && (kn[g] != ks[g]);
+        upd[g] = tail[g] && (ks[g] != prevkey);  // the run's head is in this tile too: complete here
         cV[g] = splat(0.f);
         cA[g] = splat(0.f);
         cw[g] = 0.f;
+        row[g].v = splat(0.f);
+        row[g].z = splat(0.f);
+        row[g].n = splat(0.f);
+        row[g].fo = splat(0.f);
+        if (upd[g]) row[g] = load_row<LAYOUT>(a.rows + (row0 + ks[g]) * (size_t)a.stride, q, kp, a.zoff);
         if (val[g]) {
           const uint32_t b = cs & bmask;
           const float4 S4 = *reinterpret_cast<const float4 *>(a.S + (size_t)b * kp + 4 * q);
@@ -383,7 +536,7 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
           cw[g] = x * a.dz_first[b];
         }
       }
-      // ---- per pass: segmented scan over the slots, carry, row update at run tails ----
+      // ---- per pass: segmented scan over the slots, carry, row update / partial at run tails ----
 #pragma unroll
       for (int g = 0; g < GROUP; ++g) {
         const uint32_t k = ks[g];
@@ -404,36 +557,14 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
           cA[g] = cA[g] + carA;
           cw[g] += carw;
         }
-        const bool tail = val[g] && (kn[g] != k);
-        if (tail) {
-          float *rp = a.rows + (row0 + k) * (size_t)a.stride;
-          if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
-            float4 V4 = *reinterpret_cast<float4 *>(rp + 4 * q);
-            const float4 gr = cV[g] - V4 * cA[g];
-            V4 = apply_rule4<RULE>(V4, gr, a.h);
-            *reinterpret_cast<float4 *>(rp + 4 * q) = V4;
-            if (q == 0) rp[kp] = apply_rule<RULE>(rp[kp], cw[g], a.h);
-          } else {
-            float4 z4 = *reinterpret_cast<float4 *>(rp + 4 * q);
-            float4 n4 = *reinterpret_cast<float4 *>(rp + kp + 4 * q);
-            const float4 w4 = ftrl_w4(z4, n4, a.h);
-            const float4 gr = cV[g] - w4 * cA[g];
-            ftrl_upd(z4.x, n4.x, w4.x, gr.x, a.h);
-            ftrl_upd(z4.y, n4.y, w4.y, gr.y, a.h);
-            ftrl_upd(z4.z, n4.z, w4.z, gr.z, a.h);
-            ftrl_upd(z4.w, n4.w, w4.w, gr.w, a.h);
-            *reinterpret_cast<float4 *>(rp + 4 * q) = z4;
-            *reinterpret_cast<float4 *>(rp + kp + 4 * q) = n4;
-            if (q == 0) {
-              float2 zn = *reinterpret_cast<float2 *>(rp + 2 * kp);
-              const float w = ftrl_w(zn.x, zn.y, a.h);
-              ftrl_upd(zn.x, zn.y, w, cw[g], a.h);
-              *reinterpret_cast<float2 *>(rp + 2 * kp) = zn;
-            }
-          }
+        if (upd[g]) {
+          update_row<LAYOUT, RULE>(a.rows + (row0 + k) * (size_t)a.stride, q, kp, a.zoff, row[g], cV[g], cA[g], cw[g], a.h);
+        } else if (tail[g]) {
+          store_part(part, q, kp, cV[g], cA[g], cw[g]);  // the run that came in from the previous tile ends here
         }
+        if (__ballot(tail[g] && !upd[g]) != 0ull) lead_state = LEAD_CLOSES;
         // carry out of the pass: the last slot, when its run continues
-        const bool open = __shfl((int)(val[g] && !tail), LAST + q) != 0;
+        const bool open = __shfl((int)(val[g] && !tail[g]), LAST + q) != 0;
         const uint32_t lk = __shfl(k, LAST + q);
         const float4 lV = shfl4(cV[g], LAST + q);
         const float4 lA = shfl4(cA[g], LAST + q);
@@ -445,11 +576,72 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
         carw = open ? lw : 0.f;
       }
     }
-    if (!carry_open) break;
-    base += 64;
-    if (base >= a.Bp) break;
-    c = sf[base + lane];
-    first_window = false;
+    if (carry_open) {  // the tile's last run continues in the next tile
+      if (carry_key == prevkey) {
+        lead_state = LEAD_THROUGH;  // the whole tile is one run, open at both ends
+        if (lane < LPR) store_part(part, q, kp, carV, carA, carw);
+      } else {
+        trail_state = 1;
+        if (lane < LPR) store_part(part + REC, q, kp, carV, carA, carw);
+      }
+    }
+  }
+  if (lane == 0) {
+    a.meta[(size_t)gt * 2] = lead_state;
+    a.meta[(size_t)gt * 2 + 1] = trail_state;
+  }
+}
+
+// Runs that cross tile boundaries: the wave of the tile holding the run's head adds the partial sums in tile order
+// (trail of the head tile, then the lead partial of every following tile up to the one where the run ends) and
+// applies the row update.
+template <int LPR, int LAYOUT, int RULE>
+__global__ __launch_bounds__(256) void k_fm_fixup(UpdArgs a) {
+  constexpr int SLOTS = WAVE / LPR;
+  constexpr int REC = 2 * LPR * 4 + 4;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, q = lane % LPR;
+  const int kp = LPR * 4;
+  const int tiles_per_field = a.Bp >> 6;
+  const int gt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gt >= a.F * tiles_per_field) return;
+  if (a.meta[(size_t)gt * 2 + 1] != 1) return;  // wave-uniform
+  const int f = gt / tiles_per_field;
+  const int t = gt - f * tiles_per_field;
+  // m = number of following tiles that hold a piece of the run
+  int m = 0;
+  for (int j0 = 1; t + j0 < tiles_per_field; j0 += 64) {
+    const int tj = t + j0 + lane;
+    const int st = tj < tiles_per_field ? a.meta[((size_t)f * tiles_per_field + tj) * 2] : LEAD_NONE;
+    const unsigned long long stop = __ballot(st != LEAD_THROUGH);
+    if (stop != 0ull) {
+      const int pos = __ffsll((long long)stop) - 1;
+      const int st_pos = __shfl(st, pos);
+      m = j0 + pos - (st_pos == LEAD_CLOSES ? 0 : 1);
+      break;
+    }
+    m = j0 + 63;
+  }
+  if (t + m >= tiles_per_field) m = tiles_per_field - 1 - t;
+  float4 aV = splat(0.f), aA = splat(0.f);
+  float aw = 0.f;
+  for (int j = slot; j <= m; j += SLOTS) {
+    const float *rec = j == 0 ? a.parts + ((size_t)gt * 2 + 1) * REC : a.parts + (size_t)(gt + j) * 2 * REC;
+    aV = aV + *reinterpret_cast<const float4 *>(rec + 4 * q);
+    aA = aA + *reinterpret_cast<const float4 *>(rec + kp + 4 * q);
+    aw += rec[2 * kp];
+  }
+#pragma unroll
+  for (int mm = LPR; mm < WAVE; mm <<= 1) {
+    aV = aV + shfl_xor4(aV, mm);
+    aA = aA + shfl_xor4(aA, mm);
+    aw += __shfl_xor(aw, mm);
+  }
+  if (lane < LPR) {
+    const uint32_t key = a.sorted[(size_t)f * a.Bp + ((size_t)t << 6) + 63] >> a.bbits;
+    float *rp = a.rows + ((size_t)a.foff[f] + key) * (size_t)a.stride;
+    const RowRegs r = load_row<LAYOUT>(rp, q, kp, a.zoff);
+    update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, aV, aA, aw, a.h);
   }
 }
 
@@ -487,7 +679,12 @@ int check_table(const fmx_table_t *t) {
   if (t->n_fields < 1 || t->n_rows < 1 || t->k < 1) return fail(FMX_ERR_ARG, "table sizes must be positive");
   if (!lpr_of(t->kp) || t->k > t->kp) return fail(FMX_ERR_SHAPE, "kp=%d must be 4/8/16/32/64 and >= k=%d", t->kp, t->k);
   if (t->layout != FMX_LAYOUT_WEIGHTS && t->layout != FMX_LAYOUT_FTRL) return fail(FMX_ERR_ARG, "unknown layout %d", t->layout);
-  const int need = (t->layout == FMX_LAYOUT_WEIGHTS ? t->kp : 2 * t->kp) + 4;
+  int need = t->kp + 4;
+  if (t->layout == FMX_LAYOUT_FTRL) {
+    if (t->z_offset % 4 || t->z_offset < t->kp + 4)
+      return fail(FMX_ERR_SHAPE, "z_offset=%d must be a multiple of 4 and >= kp + 4 = %d", t->z_offset, t->kp + 4);
+    need = t->z_offset + 2 * t->kp;
+  }
   if (t->row_stride % 4 || t->row_stride < need)
     return fail(FMX_ERR_SHAPE, "row_stride=%d must be a multiple of 4 and >= %d", t->row_stride, need);
   if (!aligned16(t->rows)) return fail(FMX_ERR_ALIGN, "table rows must be 16-byte aligned");
@@ -518,11 +715,48 @@ int check_sort_geometry(const fmx_table_t *t, int B) {
   return FMX_OK;
 }
 
+// ---- workspace carving: [ sorted u32 F*Bp | meta i32 F*tiles*2 | parts f32 F*tiles*2*REC ], each 256-byte aligned ----
+struct Workspace {
+  uint32_t *sorted;
+  int32_t *meta;
+  float *parts;
+  size_t bytes;
+};
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+Workspace carve(const fmx_table_t *t, int B, void *base) {
+  const size_t F = (size_t)t->n_fields, Bp = (size_t)fmx_sorted_width(B), tiles = Bp >> 6;
+  const size_t rec = 2 * (size_t)t->kp + 4;
+  const size_t o_meta = align_up(F * Bp * 4, 256);
+  const size_t o_parts = o_meta + align_up(F * tiles * 2 * 4, 256);
+  Workspace w;
+  char *p = static_cast<char *>(base);
+  w.sorted = reinterpret_cast<uint32_t *>(p);
+  w.meta = reinterpret_cast<int32_t *>(p + o_meta);
+  w.parts = reinterpret_cast<float *>(p + o_parts);
+  w.bytes = o_parts + align_up(F * tiles * 2 * rec * 4, 256);
+  return w;
+}
+
+template <int LPR, int NPASS>
+void launch_forward_np(const FwdArgs &a, int layout, hipStream_t st) {
+  const dim3 grid((a.B + 3) / 4), block(256);
+  if (layout == FMX_LAYOUT_WEIGHTS) hipLaunchKernelGGL((k_fm_forward<LPR, FMX_LAYOUT_WEIGHTS, NPASS>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((k_fm_forward<LPR, FMX_LAYOUT_FTRL, NPASS>), grid, block, 0, st, a);
+}
+
 template <int LPR>
 void launch_forward(const FwdArgs &a, int layout, hipStream_t st) {
-  const dim3 grid((a.B + 3) / 4), block(256);
-  if (layout == FMX_LAYOUT_WEIGHTS) hipLaunchKernelGGL((k_fm_forward<LPR, FMX_LAYOUT_WEIGHTS>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((k_fm_forward<LPR, FMX_LAYOUT_FTRL>), grid, block, 0, st, a);
+  const int slots = WAVE / LPR;
+  const int np = (a.F + slots - 1) / slots;
+  switch (np) {
+    case 1: launch_forward_np<LPR, 1>(a, layout, st); break;
+    case 2: launch_forward_np<LPR, 2>(a, layout, st); break;
+    case 3: launch_forward_np<LPR, 3>(a, layout, st); break;
+    case 4: launch_forward_np<LPR, 4>(a, layout, st); break;
+    default: launch_forward_np<LPR, 0>(a, layout, st); break;
+  }
 }
 
 template <int LPR, bool HAS_GBI>
@@ -542,15 +776,157 @@ void launch_update(const UpdArgs &a, int rule, hipStream_t st) {
   }
 }
 
-template <bool HAS_GBI>
-void launch_update_lpr(const UpdArgs &a, int rule, int lpr, hipStream_t st) {
-  switch (lpr) {
-    case 1: launch_update<1, HAS_GBI>(a, rule, st); break;
-    case 2: launch_update<2, HAS_GBI>(a, rule, st); break;
-    case 4: launch_update<4, HAS_GBI>(a, rule, st); break;
-    case 8: launch_update<8, HAS_GBI>(a, rule, st); break;
-    default: launch_update<16, HAS_GBI>(a, rule, st); break;
+template <int LPR>
+void launch_fixup(const UpdArgs &a, int rule, hipStream_t st) {
+  const int tiles = a.F * (a.Bp >> 6);
+  const dim3 grid((tiles + 3) / 4), block(256);
+  switch (rule) {
+    case FMX_RULE_SIGNADAM:
+      hipLaunchKernelGGL((k_fm_fixup<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM>), grid, block, 0, st, a);
+      break;
+    case FMX_RULE_SGD:
+      hipLaunchKernelGGL((k_fm_fixup<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD>), grid, block, 0, st, a);
+      break;
+    default:
+      hipLaunchKernelGGL((k_fm_fixup<LPR, FMX_LAYOUT_FTRL, FMX_RULE_FTRL>), grid, block, 0, st, a);
+      break;
   }
+}
+
+template <int LPR>
+void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st, hipEvent_t mid) {
+  if (has_gbi) launch_update<LPR, true>(a, rule, st);
+  else launch_update<LPR, false>(a, rule, st);
+  if (mid) (void)hipEventRecord(mid, st);
+  launch_fixup<LPR>(a, rule, st);
+}
+
+template <int E>
+void launch_sort(const SortArgs &a, hipStream_t st) {
+  const int threads = a.Bp / E;
+  hipLaunchKernelGGL((k_sort_occ<E>), dim3(a.F), dim3(threads), (size_t)a.Bp * sizeof(uint32_t), st, a);
+}
+
+int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t *sorted, int32_t *error, hipStream_t st) {
+  SortArgs a;
+  a.idx = idx;
+  a.foff = table->field_offsets;
+  a.sorted = sorted;
+  a.error = error;
+  a.B = B;
+  a.F = table->n_fields;
+  a.Bp = fmx_sorted_width(B);
+  a.bbits = fmx_sorted_bbits(B);
+  if ((size_t)a.Bp * 4 > 64 * 1024) {
+    static thread_local bool raised = false;
+    if (!raised) {
+      hipError_t e = hipSuccess;
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<8>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<16>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<32>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+      if (e != hipSuccess) return fail(FMX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+      raised = true;
+    }
+  }
+  // E elements per thread, Bp / E threads (a multiple of 64, at most 1024)
+  if (a.Bp <= 64) launch_sort<1>(a, st);
+  else if (a.Bp <= 128) launch_sort<2>(a, st);
+  else if (a.Bp <= 4096) launch_sort<4>(a, st);
+  else if (a.Bp <= 8192) launch_sort<8>(a, st);
+  else if (a.Bp <= 16384) launch_sort<16>(a, st);
+  else launch_sort<32>(a, st);
+  return check_launch("k_sort_occ");
+}
+
+int forward_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *xv, const float *y,
+                 int32_t B, int32_t loss_kind, float inv_b, const fmx_fwd_out_t *out, hipStream_t st) {
+  FwdArgs a;
+  a.rows = table->rows;
+  a.foff = table->field_offsets;
+  a.bias = table->bias;
+  a.idx = idx;
+  a.xv = xv;
+  a.y = y;
+  a.out = *out;
+  a.h = *hyper;
+  a.B = B;
+  a.F = table->n_fields;
+  a.kp = table->kp;
+  a.stride = table->row_stride;
+  a.zoff = table->z_offset;
+  a.loss_kind = loss_kind;
+  a.h.alpha = 1.0f / hyper->alpha;  // the kernels multiply by 1/alpha
+  a.inv_b = inv_b;
+  switch (lpr_of(table->kp)) {
+    case 1: launch_forward<1>(a, table->layout, st); break;
+    case 2: launch_forward<2>(a, table->layout, st); break;
+    case 4: launch_forward<4>(a, table->layout, st); break;
+    case 8: launch_forward<8>(a, table->layout, st); break;
+    default: launch_forward<16>(a, table->layout, st); break;
+  }
+  return check_launch("k_fm_forward");
+}
+
+int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const Workspace &w, const float *xv,
+                const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
+                const float *loss_b, float inv_b, float *loss_out, hipStream_t st, hipEvent_t mid) {
+  UpdArgs a;
+  a.rows = table->rows;
+  a.foff = table->field_offsets;
+  a.bias = table->bias;
+  a.sorted = w.sorted;
+  a.parts = w.parts;
+  a.meta = w.meta;
+  a.xv = xv;
+  a.S = S;
+  a.dz_first = dz_first;
+  a.dz_bi = dz_bi;
+  a.gbi = gbi;
+  a.loss_b = loss_b;
+  a.loss_out = loss_out;
+  a.h = *hyper;
+  a.B = B;
+  a.F = table->n_fields;
+  a.Bp = fmx_sorted_width(B);
+  a.bbits = fmx_sorted_bbits(B);
+  a.kp = table->kp;
+  a.stride = table->row_stride;
+  a.zoff = table->z_offset;
+  a.h.alpha = 1.0f / hyper->alpha;  // the kernels multiply by 1/alpha
+  a.inv_b = inv_b;
+  switch (lpr_of(table->kp)) {
+    case 1: launch_update_pair<1>(a, rule, gbi != nullptr, st, mid); break;
+    case 2: launch_update_pair<2>(a, rule, gbi != nullptr, st, mid); break;
+    case 4: launch_update_pair<4>(a, rule, gbi != nullptr, st, mid); break;
+    case 8: launch_update_pair<8>(a, rule, gbi != nullptr, st, mid); break;
+    default: launch_update_pair<16>(a, rule, gbi != nullptr, st, mid); break;
+  }
+  return check_launch("k_fm_update / k_fm_fixup");
+}
+
+int check_forward_args(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *y, int32_t B,
+                       int32_t loss_kind, const fmx_fwd_out_t *out) {
+  if (int rc = check_table(table)) return rc;
+  if (!hyper || !idx || !out) return fail(FMX_ERR_ARG, "fmx_fm_forward: null argument");
+  if (B < 1) return fail(FMX_ERR_ARG, "B must be >= 1");
+  if (loss_kind < FMX_LOSS_NONE || loss_kind > FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "unknown loss %d", loss_kind);
+  if (loss_kind != FMX_LOSS_NONE && !y) return fail(FMX_ERR_ARG, "a loss needs labels y");
+  if ((out->S && !aligned16(out->S)) || (out->bi && !aligned16(out->bi)))
+    return fail(FMX_ERR_ALIGN, "S and bi must be 16-byte aligned");
+  return FMX_OK;
+}
+
+int check_step_args(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind, int32_t B,
+                    const void *workspace, const fmx_fwd_out_t *fwd) {
+  if (int rc = check_table(table)) return rc;
+  if (int rc = check_rule(table, rule)) return rc;
+  if (int rc = check_sort_geometry(table, B)) return rc;
+  if (!hyper || !workspace) return fail(FMX_ERR_ARG, "null hyper / workspace");
+  if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
+  if (!fwd || !fwd->S || !fwd->dz || !fwd->loss) return fail(FMX_ERR_ARG, "fwd->S, fwd->loss, fwd->dz are required");
+  if (!aligned16(fwd->S)) return fail(FMX_ERR_ALIGN, "S must be 16-byte aligned");
+  if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "a step needs a loss");
+  return FMX_OK;
 }
 
 }  // namespace
@@ -576,173 +952,101 @@ int fmx_sorted_bbits(int B) {
   return bits;
 }
 
+int64_t fmx_workspace_bytes(const fmx_table_t *table, int32_t B) {
+  if (check_table(table) != FMX_OK) return FMX_ERR_ARG;
+  if (B < 1) return fail(FMX_ERR_ARG, "B must be >= 1");
+  return (int64_t)carve(table, B, nullptr).bytes;
+}
+
 int fmx_fm_forward(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *xv,
                    const float *y, int32_t B, int32_t loss_kind, float inv_b, const fmx_fwd_out_t *out,
                    fmx_stream_t stream) {
-  if (int rc = check_table(table)) return rc;
-  if (!hyper || !idx || !out) return fail(FMX_ERR_ARG, "fmx_fm_forward: null argument");
-  if (B < 1) return fail(FMX_ERR_ARG, "B must be >= 1");
-  if (loss_kind < FMX_LOSS_NONE || loss_kind > FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "unknown loss %d", loss_kind);
-  if (loss_kind != FMX_LOSS_NONE && !y) return fail(FMX_ERR_ARG, "a loss needs labels y");
-  if ((out->S && !aligned16(out->S)) || (out->bi && !aligned16(out->bi)))
-    return fail(FMX_ERR_ALIGN, "S and bi must be 16-byte aligned");
-  FwdArgs a;
-  a.rows = table->rows;
-  a.foff = table->field_offsets;
-  a.bias = table->bias;
-  a.idx = idx;
-  a.xv = xv;
-  a.y = y;
-  a.out = *out;
-  a.h = *hyper;
-  a.B = B;
-  a.F = table->n_fields;
-  a.kp = table->kp;
-  a.stride = table->row_stride;
-  a.loss_kind = loss_kind;
-  a.inv_b = inv_b;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (lpr_of(table->kp)) {
-    case 1: launch_forward<1>(a, table->layout, st); break;
-    case 2: launch_forward<2>(a, table->layout, st); break;
-    case 4: launch_forward<4>(a, table->layout, st); break;
-    case 8: launch_forward<8>(a, table->layout, st); break;
-    default: launch_forward<16>(a, table->layout, st); break;
-  }
-  return check_launch("k_fm_forward");
+  if (int rc = check_forward_args(table, hyper, idx, y, B, loss_kind, out)) return rc;
+  return forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, out, static_cast<hipStream_t>(stream));
 }
 
-int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t *sorted, int32_t *error,
+int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, void *workspace, int32_t *error,
                          fmx_stream_t stream) {
   if (int rc = check_table(table)) return rc;
-  if (!idx || !sorted) return fail(FMX_ERR_ARG, "fmx_sort_occurrences: null argument");
+  if (!idx || !workspace) return fail(FMX_ERR_ARG, "fmx_sort_occurrences: null argument");
+  if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
   if (int rc = check_sort_geometry(table, B)) return rc;
-  SortArgs a;
-  a.idx = idx;
-  a.foff = table->field_offsets;
-  a.sorted = sorted;
-  a.error = error;
-  a.B = B;
-  a.F = table->n_fields;
-  a.Bp = fmx_sorted_width(B);
-  a.bbits = fmx_sorted_bbits(B);
-  const size_t lds = (size_t)a.Bp * sizeof(uint32_t);
-  if (lds > 64 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
-      if (e != hipSuccess) return fail(FMX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-      raised = true;
-    }
-  }
-  int threads = a.Bp / 2;
-  if (threads > 1024) threads = 1024;
-  if (threads < 64) threads = 64;
-  hipLaunchKernelGGL(k_sort_occ, dim3(a.F), dim3(threads), lds, static_cast<hipStream_t>(stream), a);
-  return check_launch("k_sort_occ");
+  return sort_impl(table, idx, B, carve(table, B, workspace).sorted, error, static_cast<hipStream_t>(stream));
 }
 
-int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const uint32_t *sorted,
-                  const float *xv, const float *S, const float *dz_first, const float *dz_bi, const float *gbi,
-                  int32_t B, const float *loss_b, float inv_b, float *loss_out, fmx_stream_t stream) {
+int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, void *workspace, const float *xv,
+                  const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
+                  const float *loss_b, float inv_b, float *loss_out, fmx_stream_t stream) {
   if (int rc = check_table(table)) return rc;
   if (int rc = check_rule(table, rule)) return rc;
-  if (!hyper || !sorted || !S || !dz_first) return fail(FMX_ERR_ARG, "fmx_fm_update: null argument");
+  if (!hyper || !workspace || !S || !dz_first) return fail(FMX_ERR_ARG, "fmx_fm_update: null argument");
   if (!dz_bi && !gbi) return fail(FMX_ERR_ARG, "fmx_fm_update: one of dz_bi / gbi is required");
   if (int rc = check_sort_geometry(table, B)) return rc;
-  if (!aligned16(S) || (gbi && !aligned16(gbi))) return fail(FMX_ERR_ALIGN, "S and gbi must be 16-byte aligned");
-  UpdArgs a;
-  a.rows = table->rows;
-  a.foff = table->field_offsets;
-  a.bias = table->bias;
-  a.sorted = sorted;
-  a.xv = xv;
-  a.S = S;
-  a.dz_first = dz_first;
-  a.dz_bi = dz_bi;
-  a.gbi = gbi;
-  a.loss_b = loss_b;
-  a.loss_out = loss_out;
-  a.h = *hyper;
-  a.B = B;
-  a.F = table->n_fields;
-  a.Bp = fmx_sorted_width(B);
-  a.bbits = fmx_sorted_bbits(B);
-  a.kp = table->kp;
-  a.stride = table->row_stride;
-  a.inv_b = inv_b;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (gbi) launch_update_lpr<true>(a, rule, lpr_of(table->kp), st);
-  else launch_update_lpr<false>(a, rule, lpr_of(table->kp), st);
-  return check_launch("k_fm_update");
+  if (!aligned16(workspace) || !aligned16(S) || (gbi && !aligned16(gbi)))
+    return fail(FMX_ERR_ALIGN, "workspace, S and gbi must be 16-byte aligned");
+  return update_impl(table, hyper, rule, carve(table, B, workspace), xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out,
+                     static_cast<hipStream_t>(stream), nullptr);
 }
 
 int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
-                const int32_t *idx, const float *xv, const float *y, int32_t B, float inv_b, uint32_t *sorted,
+                const int32_t *idx, const float *xv, const float *y, int32_t B, float inv_b, void *workspace,
                 const fmx_fwd_out_t *fwd, float *loss_out, fmx_stream_t stream) {
-  if (int rc = check_table(table)) return rc;
-  if (int rc = check_rule(table, rule)) return rc;
-  if (!fwd || !fwd->S || !fwd->dz || !fwd->loss) return fail(FMX_ERR_ARG, "fmx_fm_step: fwd->S, fwd->loss, fwd->dz are required");
-  if (loss_kind == FMX_LOSS_NONE) return fail(FMX_ERR_ARG, "fmx_fm_step needs a loss");
-  if (int rc = fmx_sort_occurrences(table, idx, B, sorted, fwd->error, stream)) return rc;
-  if (int rc = fmx_fm_forward(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, stream)) return rc;
-  return fmx_fm_update(table, hyper, rule, sorted, xv, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b, loss_out,
-                       stream);
+  if (int rc = check_step_args(table, hyper, rule, loss_kind, B, workspace, fwd)) return rc;
+  if (!idx || !y) return fail(FMX_ERR_ARG, "fmx_fm_step: idx and y are required");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const Workspace w = carve(table, B, workspace);
+  if (int rc = sort_impl(table, idx, B, w.sorted, fwd->error, st)) return rc;
+  if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
+  return update_impl(table, hyper, rule, w, xv, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b, loss_out, st, nullptr);
 }
 
 int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
                   const int32_t *idx_pool, const float *y_pool, int32_t n_pool, int32_t B, float inv_b,
-                  int32_t n_steps, uint32_t *sorted, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
+                  int32_t n_steps, void *workspace, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
                   fmx_stream_t stream) {
-  if (int rc = check_table(table)) return rc;
+  if (int rc = check_step_args(table, hyper, rule, loss_kind, B, workspace, fwd)) return rc;
   if (!idx_pool || !y_pool || n_pool < 1 || n_steps < 0) return fail(FMX_ERR_ARG, "fmx_fm_stream: bad pool / step count");
-  if (!fwd || !fwd->S || !fwd->dz || !fwd->loss) return fail(FMX_ERR_ARG, "fmx_fm_stream: fwd->S, fwd->loss, fwd->dz are required");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const Workspace w = carve(table, B, workspace);
   const size_t F = (size_t)table->n_fields;
-  if (!kernel_ms) {
-    for (int s = 0; s < n_steps; ++s) {
-      const int j = s % n_pool;
-      if (int rc = fmx_fm_step(table, hyper, rule, loss_kind, idx_pool + (size_t)j * B * F, nullptr, y_pool + (size_t)j * B,
-                               B, inv_b, sorted, fwd, loss_out ? loss_out + s : nullptr, stream))
-        return rc;
-    }
-    return FMX_OK;
+  const int n_ev = 5;
+  hipEvent_t *ev = nullptr;
+  if (kernel_ms) {  // timing mode: HIP events on the launch stream around every kernel
+    ev = new hipEvent_t[(size_t)n_steps * n_ev];
+    for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventCreate(&ev[i]);
   }
-  // timing mode: HIP events on the launch stream around every kernel
-  const int n_ev = 4;
-  hipEvent_t *ev = new hipEvent_t[(size_t)n_steps * n_ev];
-  for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventCreate(&ev[i]);
   int rc = FMX_OK;
   for (int s = 0; s < n_steps && rc == FMX_OK; ++s) {
     const int j = s % n_pool;
     const int32_t *idx = idx_pool + (size_t)j * B * F;
     const float *y = y_pool + (size_t)j * B;
-    hipEvent_t *e = ev + (size_t)s * n_ev;
-    (void)hipEventRecord(e[0], st);
-    rc = fmx_sort_occurrences(table, idx, B, sorted, fwd->error, stream);
-    (void)hipEventRecord(e[1], st);
-    if (rc == FMX_OK) rc = fmx_fm_forward(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, stream);
-    (void)hipEventRecord(e[2], st);
+    hipEvent_t *e = ev ? ev + (size_t)s * n_ev : nullptr;
+    if (e) (void)hipEventRecord(e[0], st);
+    rc = sort_impl(table, idx, B, w.sorted, fwd->error, st);
+    if (e) (void)hipEventRecord(e[1], st);
+    if (rc == FMX_OK) rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
+    if (e) (void)hipEventRecord(e[2], st);
     if (rc == FMX_OK)
-      rc = fmx_fm_update(table, hyper, rule, sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                         loss_out ? loss_out + s : nullptr, stream);
-    (void)hipEventRecord(e[3], st);
+      rc = update_impl(table, hyper, rule, w, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
+                       loss_out ? loss_out + s : nullptr, st, e ? e[3] : nullptr);
+    if (e) (void)hipEventRecord(e[4], st);
   }
-  (void)hipStreamSynchronize(st);
-  kernel_ms[0] = kernel_ms[1] = kernel_ms[2] = 0.f;
-  if (rc == FMX_OK) {
-    for (int s = 0; s < n_steps; ++s) {
-      hipEvent_t *e = ev + (size_t)s * n_ev;
-      for (int k = 0; k < 3; ++k) {
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e[k], e[k + 1]);
-        kernel_ms[k] += ms;
+  if (ev) {
+    (void)hipStreamSynchronize(st);
+    for (int k = 0; k < 4; ++k) kernel_ms[k] = 0.f;
+    if (rc == FMX_OK) {
+      for (int s = 0; s < n_steps; ++s) {
+        hipEvent_t *e = ev + (size_t)s * n_ev;
+        for (int k = 0; k < 4; ++k) {
+          float ms = 0.f;
+          (void)hipEventElapsedTime(&ms, e[k], e[k + 1]);
+          kernel_ms[k] += ms;
+        }
       }
     }
+    for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventDestroy(ev[i]);
+    delete[] ev;
   }
-  for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventDestroy(ev[i]);
-  delete[] ev;
   return rc;
 }
 

@@ -14,7 +14,8 @@ LOSS_NONE, LOSS_BCE_LOGITS, LOSS_BCE_SIGMOID = 0, 1, 2
 RULES = {"signadam": RULE_SIGNADAM, "sgd": RULE_SGD, "ftrl": RULE_FTRL}
 LOSSES = {None: LOSS_NONE, "none": LOSS_NONE, "logits": LOSS_BCE_LOGITS, "sigmoid": LOSS_BCE_SIGMOID}
 
-EXPORTS = ["fmx_version", "fmx_last_error_string", "fmx_sorted_width", "fmx_sorted_bbits", "fmx_fm_forward",
+EXPORTS = ["fmx_version", "fmx_last_error_string", "fmx_sorted_width", "fmx_sorted_bbits", "fmx_workspace_bytes",
+           "fmx_fm_forward",
            "fmx_sort_occurrences", "fmx_fm_update", "fmx_fm_step", "fmx_fm_stream", "fmx_stream_read"]
 
 
@@ -27,7 +28,7 @@ class FmxError(RuntimeError):
 class Table(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("field_offsets", C.c_void_p), ("bias", C.c_void_p), ("n_rows", C.c_int64),
                 ("n_fields", C.c_int32), ("k", C.c_int32), ("kp", C.c_int32), ("row_stride", C.c_int32),
-                ("layout", C.c_int32), ("reserved", C.c_int32), ("max_field_rows", C.c_int64)]
+                ("layout", C.c_int32), ("z_offset", C.c_int32), ("max_field_rows", C.c_int64)]
 
 
 class Hyper(C.Structure):
@@ -57,6 +58,7 @@ def load():
     lib.fmx_last_error_string.restype = C.c_char_p
     lib.fmx_sorted_width.argtypes = [C.c_int]
     lib.fmx_sorted_bbits.argtypes = [C.c_int]
+    lib.fmx_workspace_bytes.argtypes = [TP, i32]
     lib.fmx_fm_forward.argtypes = [TP, HP, p, p, p, i32, i32, f32, FP, p]
     lib.fmx_sort_occurrences.argtypes = [TP, p, i32, p, p, p]
     lib.fmx_fm_update.argtypes = [TP, HP, i32, p, p, p, p, p, p, i32, p, f32, p, p]
@@ -65,7 +67,9 @@ def load():
     lib.fmx_stream_read.argtypes = [p, i64, p, p]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("fmx_last_error_string",):
+        if name == "fmx_workspace_bytes":
+            fn.restype = C.c_int64
+        elif name != "fmx_last_error_string":
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -54,7 +54,11 @@ class FMEngine:
         t, dev = self.table, self.device
         Bp = self.lib.fmx_sorted_width(B)
         f32 = dict(dtype=torch.float32, device=dev)
-        self.sorted = torch.empty((t.n_fields, Bp), dtype=torch.int32, device=dev)
+        nbytes = int(self.lib.fmx_workspace_bytes(t.c_struct(), B))
+        if nbytes < 0:
+            _lib.check(nbytes)
+        self.workspace = torch.zeros(nbytes // 4, dtype=torch.int32, device=dev)
+        self.sorted = self.workspace[:t.n_fields * Bp].view(t.n_fields, Bp)     # the occurrence lists (uint32 bits)
         self.S = torch.empty((B, t.kp), **f32)
         self.bi = torch.empty((B, t.kp), **f32)
         self.first = torch.empty((B, t.n_fields), **f32)
@@ -103,12 +107,12 @@ class FMEngine:
     def sort(self, idx_d):
         B = idx_d.shape[0]
         self._ensure(B)
-        _lib.check(self.lib.fmx_sort_occurrences(self.table.c_struct(), idx_d.data_ptr(), B, self.sorted.data_ptr(),
+        _lib.check(self.lib.fmx_sort_occurrences(self.table.c_struct(), idx_d.data_ptr(), B, self.workspace.data_ptr(),
                                                  self.error.data_ptr(), self._stream()))
 
     def update(self, hyper, rule, B, xv_d, dz_first, dz_bi=None, gbi=None, inv_b=None, with_loss=True):
         inv_b = 1.0 / B if inv_b is None else inv_b
-        _lib.check(self.lib.fmx_fm_update(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], self.sorted.data_ptr(),
+        _lib.check(self.lib.fmx_fm_update(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], self.workspace.data_ptr(),
                                           _ptr(xv_d), self.S.data_ptr(), dz_first.data_ptr(), _ptr(dz_bi), _ptr(gbi), B,
                                           self.loss_b.data_ptr() if with_loss else None, inv_b,
                                           self.loss_out.data_ptr() if with_loss else None, self._stream()))
@@ -120,7 +124,7 @@ class FMEngine:
         out = self._fwd_out(want_first=False, want_bi=False)
         inv_b = 1.0 / B if inv_b is None else inv_b
         _lib.check(self.lib.fmx_fm_step(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss],
-                                        idx_d.data_ptr(), _ptr(xv_d), y_d.data_ptr(), B, inv_b, self.sorted.data_ptr(),
+                                        idx_d.data_ptr(), _ptr(xv_d), y_d.data_ptr(), B, inv_b, self.workspace.data_ptr(),
                                         C.byref(out), self.loss_out.data_ptr(), self._stream()))
 
     def stream(self, hyper, rule, loss, idx_pool, y_pool, n_steps, loss_out=None, timed=False):
@@ -129,10 +133,10 @@ class FMEngine:
         assert F == self.table.n_fields and y_pool.shape == (n_pool, B)
         self._ensure(B)
         out = self._fwd_out(want_first=False, want_bi=False)
-        ms = (C.c_float * 3)() if timed else None
+        ms = (C.c_float * 4)() if timed else None
         _lib.check(self.lib.fmx_fm_stream(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss],
                                           idx_pool.data_ptr(), y_pool.data_ptr(), n_pool, B, 1.0 / B, n_steps,
-                                          self.sorted.data_ptr(), C.byref(out), _ptr(loss_out), ms, self._stream()))
+                                          self.workspace.data_ptr(), C.byref(out), _ptr(loss_out), ms, self._stream()))
         return None if ms is None else [float(v) for v in ms]
 
     def check_error_flag(self):

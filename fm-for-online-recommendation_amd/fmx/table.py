@@ -2,10 +2,11 @@
 
 The reference keeps 2 x 39 nn.Embedding modules (reference fm_adam.py:29-32).  Here field f owns rows
 [offsets[f], offsets[f+1]) of a single [R, row_stride] fp32 buffer, so a sample's 39 active features are 39 row
-gathers of one 64-byte-aligned record each (layouts in include/fmx.h):
+gathers of one 64-byte request each, inside one 128-byte line (layouts in include/fmx.h):
 
-    weights layout   [ V[0..kp) | w | pad ]                     (rules 'signadam', 'sgd')
-    ftrl layout      [ zV[0..kp) | nV[0..kp) | zw | nw | pad ]  (rule 'ftrl'; the weights are derived, never stored)
+    weights layout   [ V[0..kp) | w | pad ]                                         (rules 'signadam', 'sgd')
+    ftrl layout      [ V[0..kp) | w, zw, nw, 0 | pad | zV[0..kp) | nV[0..kp) ]      (rule 'ftrl'; state is (z, n), V and
+                                                                                     w are the weights derived from it)
 """
 import ctypes as C
 
@@ -33,8 +34,19 @@ def field_offsets(feature_sizes):
     return np.concatenate([[0], np.cumsum(sizes, dtype=np.int64)]).astype(np.int64)
 
 
+def ftrl_weight_torch(z, n, h):
+    """w(z, n) of FTRL-proximal in torch (host-side plumbing for import / export; the kernels have their own)."""
+    w = -(z - torch.sign(z) * h["l1"]) / ((h["beta"] + torch.sqrt(n)) / h["alpha"] + h["l2"])
+    return torch.where(z.abs() <= h["l1"], torch.zeros_like(w), w)
+
+
+def ftrl_z_for_weight_torch(w, h):
+    """z with ftrl_weight(z, n=0) == w: FTRL starts from given weights (FM needs V != 0 to learn at all)."""
+    return -w * (h["beta"] / h["alpha"] + h["l2"]) - torch.sign(w) * h["l1"]
+
+
 class FlatTable:
-    def __init__(self, feature_sizes, k, layout="weights", device=None, row_stride=None):
+    def __init__(self, feature_sizes, k, layout="weights", device=None, row_stride=None, ftrl=None):
         if device is None:
             device = torch.device("cuda")
         self.device = torch.device(device)
@@ -45,8 +57,20 @@ class FlatTable:
         self.layout = layout
         if layout not in ("weights", "ftrl"):
             raise ValueError(layout)
-        need = (self.kp if layout == "weights" else 2 * self.kp) + 4
-        self.row_stride = _round_up(need, 16) if row_stride is None else int(row_stride)
+        self.ftrl = dict(alpha=0.05, beta=1.0, l1=0.0, l2=0.0)
+        if ftrl:
+            self.ftrl.update({k_: float(v) for k_, v in ftrl.items() if k_ in self.ftrl})
+        kp = self.kp
+        if layout == "weights":
+            self.z_offset = 0
+            need = kp + 4
+            default = _round_up(need, 32) if kp >= 16 else 2 * kp      # k = 16: one 128-byte line per row
+        else:
+            # the (z, n) half starts on its own 128-byte line for kp >= 16; smaller rows share one line
+            self.z_offset = _round_up(kp + 4, 32) if kp >= 16 else 2 * kp
+            need = self.z_offset + 2 * kp
+            default = _round_up(need, 32) if kp >= 16 else 4 * kp
+        self.row_stride = default if row_stride is None else int(row_stride)
         if self.row_stride % 4 or self.row_stride < need:
             raise ValueError(f"row_stride must be a multiple of 4 and >= {need}")
         offs = field_offsets(self.feature_sizes)
@@ -68,18 +92,19 @@ class FlatTable:
             t.n_fields = self.n_fields
             t.k, t.kp, t.row_stride = self.k, self.kp, self.row_stride
             t.layout = _lib.LAYOUT_WEIGHTS if self.layout == "weights" else _lib.LAYOUT_FTRL
+            t.z_offset = self.z_offset
             t.max_field_rows = max(self.feature_sizes)
             self._cstruct = t
         return C.byref(self._cstruct)
 
-    # ---- strided views into the flat buffer (weights layout) ----
+    # ---- strided views into the flat buffer (both layouts keep [ V | w ] at the head of the row) ----
     @property
     def V(self):
         return self.rows[:, :self.k]
 
     @property
     def w(self):
-        return self.rows[:, self.kp if self.layout == "weights" else 2 * self.kp]
+        return self.rows[:, self.kp]
 
     def field_V(self, f):
         lo, hi = int(self.offsets_host[f]), int(self.offsets_host[f + 1])
@@ -89,20 +114,24 @@ class FlatTable:
         lo, hi = int(self.offsets_host[f]), int(self.offsets_host[f + 1])
         return self.rows[lo:hi, self.kp:self.kp + 1]
 
-    # ---- reference-shaped import / export (weights layout) ----
+    # ---- reference-shaped import / export ----
     def load_reference(self, first_list, second_list):
-        """first_list[f]: [size_f, 1]; second_list[f]: [size_f, k] (reference nn.Embedding weights)."""
-        assert self.layout == "weights"
+        """first_list[f]: [size_f, 1]; second_list[f]: [size_f, k] (reference nn.Embedding weights).
+        FTRL layout: n = 0 and the z that reproduces these weights."""
         V = torch.cat([torch.as_tensor(t, dtype=torch.float32).reshape(s, self.k)
-                       for t, s in zip(second_list, self.feature_sizes)])
+                       for t, s in zip(second_list, self.feature_sizes)]).to(self.device)
         w = torch.cat([torch.as_tensor(t, dtype=torch.float32).reshape(s)
-                       for t, s in zip(first_list, self.feature_sizes)])
-        self.rows.zero_()
-        self.rows[:, :self.k] = V.to(self.device)
-        self.rows[:, self.kp] = w.to(self.device)
+                       for t, s in zip(first_list, self.feature_sizes)]).to(self.device)
+        if self.layout == "weights":
+            self.rows.zero_()
+            self.rows[:, :self.k] = V
+            self.rows[:, self.kp] = w
+        else:
+            self.load_ftrl_state(ftrl_z_for_weight_torch(V, self.ftrl), torch.zeros_like(V),
+                                 ftrl_z_for_weight_torch(w, self.ftrl), torch.zeros_like(w))
 
     def export_reference(self):
-        assert self.layout == "weights"
+        """Per-field (first [size,1], second [size,k]) weights on the CPU (for FTRL: the derived weights)."""
         rows = self.rows.detach().cpu()
         first, second = [], []
         for f in range(self.n_fields):
@@ -111,18 +140,36 @@ class FlatTable:
             second.append(rows[lo:hi, :self.k].clone())
         return first, second
 
-    # ---- ftrl layout helpers ----
+    # ---- ftrl layout: (z, n) state; V and w are re-derived here exactly as the kernels do after an update ----
     def load_ftrl_state(self, zV, nV, zw, nw):
         assert self.layout == "ftrl"
-        kp, k = self.kp, self.k
+        kp, k, zo, dev = self.kp, self.k, self.z_offset, self.device
+        zV, nV = torch.as_tensor(zV, dtype=torch.float32).to(dev), torch.as_tensor(nV, dtype=torch.float32).to(dev)
+        zw, nw = torch.as_tensor(zw, dtype=torch.float32).to(dev), torch.as_tensor(nw, dtype=torch.float32).to(dev)
         self.rows.zero_()
-        self.rows[:, :k] = torch.as_tensor(zV, dtype=torch.float32).to(self.device)
-        self.rows[:, kp:kp + k] = torch.as_tensor(nV, dtype=torch.float32).to(self.device)
-        self.rows[:, 2 * kp] = torch.as_tensor(zw, dtype=torch.float32).to(self.device)
-        self.rows[:, 2 * kp + 1] = torch.as_tensor(nw, dtype=torch.float32).to(self.device)
+        self.rows[:, zo:zo + k] = zV
+        self.rows[:, zo + kp:zo + kp + k] = nV
+        self.rows[:, kp + 1] = zw
+        self.rows[:, kp + 2] = nw
+        self.rows[:, :k] = ftrl_weight_torch(zV, nV, self.ftrl)
+        self.rows[:, kp] = ftrl_weight_torch(zw, nw, self.ftrl)
 
     def export_ftrl_state(self):
         assert self.layout == "ftrl"
-        kp, k = self.kp, self.k
+        kp, k, zo = self.kp, self.k, self.z_offset
         r = self.rows.detach().cpu()
-        return (r[:, :k].clone(), r[:, kp:kp + k].clone(), r[:, 2 * kp].clone(), r[:, 2 * kp + 1].clone())
+        return (r[:, zo:zo + k].clone(), r[:, zo + kp:zo + kp + k].clone(), r[:, kp + 1].clone(), r[:, kp + 2].clone())
+
+    def bias_weight(self):
+        """The bias as a 0-d device tensor (FTRL: derived from its (z, n) pair)."""
+        if self.layout == "weights":
+            return self.bias[0]
+        return ftrl_weight_torch(self.bias[0], self.bias[1], self.ftrl)
+
+    def set_bias_weight(self, value):
+        value = float(value)
+        if self.layout == "weights":
+            self.bias[0] = value
+        else:
+            self.bias[0] = float(ftrl_z_for_weight_torch(torch.tensor(value), self.ftrl))
+            self.bias[1] = 0.0

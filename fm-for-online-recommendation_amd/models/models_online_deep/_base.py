@@ -79,7 +79,7 @@ class OnlineFMBase(nn.Module):
         if ftrl:
             self._ftrl.update(ftrl)
         self._table = fmx.FlatTable(feature_sizes, embedding_size, layout="ftrl" if update_rule == "ftrl" else "weights",
-                                    device=self.device)
+                                    device=self.device, ftrl=self._ftrl)
         self._load_weights(first, second, bias0)
         del first, second
         self._engine = fmx.FMEngine(self._table, max_batch=max(int(batch_size), 64))
@@ -102,48 +102,16 @@ class OnlineFMBase(nn.Module):
     # table <-> reference-shaped weights
     # ------------------------------------------------------------------------------------------------------
     def _load_weights(self, first, second, bias):
-        t = self._table
-        bias = float(torch.as_tensor(bias).reshape(-1)[0])
-        if t.layout == "weights":
-            t.load_reference(first, second)
-            t.bias[0] = bias
-            return
-        # FTRL-proximal keeps (z, n) only: start from n = 0 and the z that reproduces the given weights
-        h = self._ftrl
-        d0 = h["beta"] / h["alpha"] + h["l2"]
-        V = torch.cat([torch.as_tensor(x, dtype=torch.float32) for x in second])
-        w = torch.cat([torch.as_tensor(x, dtype=torch.float32).reshape(-1) for x in first])
-        t.load_ftrl_state(-V * d0 - torch.sign(V) * h["l1"], torch.zeros_like(V), -w * d0 - torch.sign(w) * h["l1"],
-                          torch.zeros_like(w))
-        t.bias[0] = -bias * d0 - float(np.sign(bias)) * h["l1"]
-        t.bias[1] = 0.0
+        self._table.load_reference(first, second)
+        self._table.set_bias_weight(float(torch.as_tensor(bias).reshape(-1)[0]))
 
     def _export_weights(self):
-        t = self._table
-        if t.layout == "weights":
-            first, second = t.export_reference()
-            return first, second, t.bias[0].detach().cpu()
-        h = self._ftrl
-        zV, nV, zw, nw = t.export_ftrl_state()
-
-        def wt(z, n):
-            w = -(z - torch.sign(z) * h["l1"]) / ((h["beta"] + torch.sqrt(n)) / h["alpha"] + h["l2"])
-            return torch.where(z.abs() <= h["l1"], torch.zeros_like(w), w)
-        V, w = wt(zV, nV), wt(zw, nw)
-        offs = t.offsets_host
-        first = [w[int(offs[f]):int(offs[f + 1])].reshape(-1, 1).clone() for f in range(t.n_fields)]
-        second = [V[int(offs[f]):int(offs[f + 1])].clone() for f in range(t.n_fields)]
-        zb = t.bias.detach().cpu()
-        return first, second, wt(zb[0:1], zb[1:2])[0]
+        first, second = self._table.export_reference()
+        return first, second, self._table.bias_weight().detach().cpu()
 
     @property
     def bias(self):
-        zb = self._table.bias
-        if self._table.layout == "weights":
-            return zb[0].reshape(self._bias_shape)
-        h = self._ftrl                       # FTRL layout: the bias is derived from its (z, n) pair
-        w = -(zb[0] - torch.sign(zb[0]) * h["l1"]) / ((h["beta"] + torch.sqrt(zb[1])) / h["alpha"] + h["l2"])
-        return torch.where(zb[0].abs() <= h["l1"], torch.zeros_like(w), w).reshape(self._bias_shape)
+        return self._table.bias_weight().reshape(self._bias_shape)
 
     def state_dict(self, *args, **kwargs):
         """The reference's keys and shapes: first_order_embeddings.{i}.weight [size_i,1],

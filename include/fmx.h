@@ -16,11 +16,16 @@
  *   - the library never throws and keeps no global mutable state besides the thread-local error string.
  *
  * Table layout in HBM (one flat buffer for all fields; field f owns rows [field_offsets[f], field_offsets[f+1])):
- *   FMX_LAYOUT_WEIGHTS  row = [ V[0..kp) | w | pad ]                 row_stride >= kp + 4
- *   FMX_LAYOUT_FTRL     row = [ zV[0..kp) | nV[0..kp) | zw | nw | pad ]   row_stride >= 2*kp + 4
+ *   FMX_LAYOUT_WEIGHTS  row = [ V[0..kp) | w | pad ]                                  row_stride >= kp + 4
+ *   FMX_LAYOUT_FTRL     row = [ V[0..kp) | w, zw, nw, 0 | pad | zV[0..kp) | nV[0..kp) ]    zV at float z_offset,
+ *                                                                                     row_stride >= z_offset + 2*kp
  * kp is k rounded up to 4, 8, 16, 32 or 64; the pad components must be zero (they then stay zero under every
- * rule).  row_stride is in floats and a multiple of 4 (16-byte rows).  In the FTRL layout the weights are never
- * stored: w = 0 if |z| <= l1 else -(z - sgn(z) l1) / ((beta + sqrt(n)) / alpha + l2)  (McMahan et al. 2013).
+ * rule).  row_stride and z_offset are in floats and multiples of 4 (16-byte pieces).  Both layouts start with the
+ * weights the forward pass reads, so a forward gather is ONE 64-byte request per row (k = 16) inside one 128-byte
+ * line.  In the FTRL layout the state is (z, n); V and w are the weights derived from it,
+ *     w = 0 if |z| <= l1 else -(z - sgn(z) l1) / ((beta + sqrt(n)) / alpha + l2)      (McMahan et al. 2013),
+ * re-derived and stored by every update -- a cache, never an independent parameter: whoever writes (z, n) or changes
+ * the hyper-parameters must rewrite V and w with the same formula.
  */
 #ifndef FMX_H
 #define FMX_H
@@ -71,7 +76,7 @@ typedef struct fmx_table {
   int32_t kp;         /* k padded to 4 / 8 / 16 / 32 / 64 */
   int32_t row_stride; /* floats */
   int32_t layout;     /* enum fmx_layout */
-  int32_t reserved;
+  int32_t z_offset;   /* FTRL: float offset of zV inside the row (multiple of 4, >= kp + 4); WEIGHTS: ignored */
   int64_t max_field_rows; /* largest per-field vocabulary (host copy; bounds the sort's composite keys) */
 } fmx_table_t;
 
@@ -100,6 +105,13 @@ const char *fmx_last_error_string(void);
 int fmx_sorted_width(int B);
 int fmx_sorted_bbits(int B);
 
+/* Bytes of caller-owned device workspace a step of batch size B needs (16-byte aligned).  Layout:
+ *   sorted  uint32 [F, Bp]           occurrence lists: (local index << bbits) | sample, padded with 0xFFFFFFFF
+ *   meta    int32  [F, Bp/64, 2]     per 64-entry tile: does a run come in from / go out to the neighbouring tile
+ *   parts   float  [F, Bp/64, 2, 2*kp+4]  partial sums of the runs that cross a tile boundary
+ * Negative on a bad table. */
+int64_t fmx_workspace_bytes(const fmx_table_t *table, int32_t B);
+
 /* Gather + bi-interaction forward.
  * Replaces: first_order / second_order / forward_fm (reference deepfm_adam.py:46-77, fm_adam.py:35-53),
  * i.e. 2 x 39 nn.Embedding gathers, the two 39-term Python sums and the bi-interaction, plus (loss_kind != NONE)
@@ -117,10 +129,12 @@ int fmx_fm_forward(const fmx_table_t *table, const fmx_hyper_t *hyper, const int
  * Replaces: the duplicate-row summation embedding_dense_backward performs inside loss.backward()
  * (reference fm_adam.py:67,81) -- sorting is what makes "reduce per unique row, then
  * update once" deterministic.
- *   sorted [F, Bp] uint32, entry = (local index << bbits) | sample, padded with 0xFFFFFFFF;
- *   Bp = fmx_sorted_width(B), bbits = fmx_sorted_bbits(B); requires (max vocabulary - 1) < (0xFFFFFFFF >> bbits).
+ *   workspace: fmx_workspace_bytes(table, B) bytes; the lists land at its start as uint32 [F, Bp],
+ *   entry = (local index << bbits) | sample, padded with 0xFFFFFFFF;
+ *   Bp = fmx_sorted_width(B), bbits = fmx_sorted_bbits(B); requires (max vocabulary - 1) < (0xFFFFFFFF >> bbits)
+ *   and Bp <= 32768 (one workgroup sorts a field in LDS).
  */
-int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t *sorted, int32_t *error,
+int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, void *workspace, int32_t *error,
                          fmx_stream_t stream);
 
 /* Row-reduced backward + fused per-row update.
@@ -129,33 +143,33 @@ int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B
  *     G[b,d]  = dz_bi[b] + gbi[b,d]                       (either term may be absent)
  *     dV[row] = sum_b x (S_b - x V_row) * G[b,:]          dw[row] = sum_b x dz_first[b]
  * summed in sample order, then ONE application of `rule` per coordinate.  The bias gets sum_b dz_first[b].
- *   sorted    from fmx_sort_occurrences for the same idx
+ *   workspace the one fmx_sort_occurrences filled for the same idx
  *   S         [B, kp] from fmx_fm_forward
  *   dz_first  [B] coefficient of the first-order weights and the bias
  *   dz_bi     [B] or null: scalar coefficient on every bi component (the FM term sum_d bi_d)
  *   gbi       [B, kp] or null: dL/dbi from a network on top of bi (DeepFM / NFM)
  *   loss_b    [B] or null with loss_out [1] or null: loss_out = inv_b * sum_b loss_b (deterministic order)
  */
-int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const uint32_t *sorted,
+int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, void *workspace,
                   const float *xv, const float *S, const float *dz_first, const float *dz_bi, const float *gbi,
                   int32_t B, const float *loss_b, float inv_b, float *loss_out, fmx_stream_t stream);
 
 /* One pure-FM mini-batch step = sort + forward(+loss) + update on one stream.
  * Replaces: FMAdam.update_embedding / FMAdam.fit (reference fm_adam.py:56-82) and every class's
  * update_embedding (deepfm_adam.py:91-104 etc.), which all train on forward_fm only.
- * Workspace (caller-owned): sorted [F, Bp] u32; fwd->S, fwd->loss, fwd->dz must be non-null. */
+ * workspace: fmx_workspace_bytes(table, B) bytes; fwd->S, fwd->loss, fwd->dz must be non-null. */
 int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
-                const int32_t *idx, const float *xv, const float *y, int32_t B, float inv_b, uint32_t *sorted,
+                const int32_t *idx, const float *xv, const float *y, int32_t B, float inv_b, void *workspace,
                 const fmx_fwd_out_t *fwd, float *loss_out, fmx_stream_t stream);
 
 /* The online loop over a device-resident stream of mini-batches: step s uses batch (s mod n_pool).
  * Replaces: the driver loops reference main_experiment.py:92-105 (pre-training) and fm_adam.py:97-99
  * (run_experiment), batched.  idx_pool [n_pool, B, F], y_pool [n_pool, B]; loss_out [n_steps] or null.
- * kernel_ms (HOST pointer, [3]) or null: when given, every launch is bracketed with HIP events on `stream` and the
- * summed durations of {sort, forward, update} in milliseconds are returned after a stream synchronise. */
+ * kernel_ms (HOST pointer, [4]) or null: when given, every launch is bracketed with HIP events on `stream` and the
+ * summed durations of {sort, forward, update, fixup} in milliseconds are returned after a stream synchronise. */
 int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
                   const int32_t *idx_pool, const float *y_pool, int32_t n_pool, int32_t B, float inv_b,
-                  int32_t n_steps, uint32_t *sorted, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
+                  int32_t n_steps, void *workspace, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
                   fmx_stream_t stream);
 
 /* Streaming read of `bytes` (multiple of 16) with 16-byte loads; sink [1] receives a checksum so the loads stay

@@ -91,7 +91,7 @@ def test_flat_table_geometry():
     assert (t.kp, t.row_stride, t.n_rows) == (16, 32, 26)
     np.testing.assert_array_equal(t.offsets_host, [0, 7, 12, 23, 26])
     t2 = fmx.FlatTable([7, 5, 11, 3], 16, layout="ftrl", device="cpu")
-    assert t2.row_stride == 48 and t2.bias.numel() == 2
+    assert (t2.z_offset, t2.row_stride, t2.bias.numel()) == (32, 64, 2)      # forward half | (z, n) half: 2 x 128 B
     with pytest.raises(ValueError):
         fmx.FlatTable([7, 0], 4, device="cpu")
     with pytest.raises(ValueError):
