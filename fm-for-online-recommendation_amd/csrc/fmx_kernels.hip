@@ -25,6 +25,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "fmx.h"
 
@@ -459,13 +460,34 @@ __device__ __forceinline__ void store_part(float *rec, int q, int kp, float4 cV,
   if (q == 0) rec[2 * kp] = cw;
 }
 
+// run sums carried per occurrence: cV = sum x G S (vector), cA = sum x^2 G (a scalar when G is one: pure FM), cw
+template <bool VEC> struct CoefA;
+template <> struct CoefA<true> {
+  float4 v;
+  __device__ __forceinline__ void zero() { v = splat(0.f); }
+  __device__ __forceinline__ void add(const CoefA &o) { v = v + o.v; }
+  __device__ __forceinline__ float4 vec() const { return v; }
+  __device__ __forceinline__ CoefA up(int d) const { return {shfl_up4(v, d)}; }
+};
+template <> struct CoefA<false> {
+  float v;
+  __device__ __forceinline__ void zero() { v = 0.f; }
+  __device__ __forceinline__ void add(const CoefA &o) { v += o.v; }
+  __device__ __forceinline__ float4 vec() const { return splat(v); }
+  __device__ __forceinline__ CoefA up(int d) const { return {__shfl_up(v, d)}; }
+};
+
+// One wave per tile of 64 sorted occurrences of one field.  Lane group s (LPR lanes; lane q owns coordinates 4q..4q+3)
+// walks EPG = 64 / SLOTS CONSECUTIVE occurrences sequentially, so duplicates inside a group are summed in registers;
+// one segmented scan over the SLOTS groups (log2(SLOTS) steps of wave shuffles) carries the sums of runs that span
+// groups.  At the tail of a run: the row update when the run began in this tile, a partial record otherwise.
 template <int LPR, int LAYOUT, int RULE, bool HAS_GBI>
 __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
-  constexpr int SLOTS = WAVE / LPR;  // occurrences handled per pass
-  constexpr int PASSES = LPR;        // passes per 64-entry tile
-  constexpr int GROUP = PASSES < 4 ? PASSES : 4;  // passes whose loads are issued together
-  constexpr int LAST = (SLOTS - 1) * LPR;          // first lane of the last slot
+  constexpr int SLOTS = WAVE / LPR;  // lane groups
+  constexpr int EPG = LPR;           // consecutive occurrences per group
   constexpr int REC = 2 * LPR * 4 + 4;
+  constexpr bool PREFETCH_ROWS = EPG <= 4;
+  using CA = CoefA<HAS_GBI>;
   if (blockIdx.x == gridDim.x - 1) {  // the last block owns the bias and the loss reduction
     bias_and_loss<LAYOUT, RULE>(a);
     return;
@@ -481,110 +503,151 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   const uint32_t *sf = a.sorted + (size_t)f * a.Bp;
   const int bbits = a.bbits;
   const uint32_t bmask = (1u << bbits) - 1u;
-  const uint32_t NOKEY = SENT >> bbits;
+  const int e0 = base + slot * EPG;
 
-  const uint32_t c = sf[base + lane];
-  const uint32_t prevkey = (base == 0 ? SENT : sf[base - 1]) >> bbits;
-  const uint32_t nextc = (base + 64 < a.Bp) ? sf[base + 64] : SENT;
+  uint32_t c[EPG];
+#pragma unroll
+  for (int j = 0; j < EPG; ++j) c[j] = sf[e0 + j];
+  const uint32_t kprev = (e0 == 0 ? SENT : sf[e0 - 1]) >> bbits;
+  const uint32_t knext = (e0 + EPG < a.Bp ? sf[e0 + EPG] : SENT) >> bbits;
+  const uint32_t tile_prevkey = (base == 0 ? SENT : sf[base - 1]) >> bbits;
   const size_t row0 = (size_t)a.foff[f];
   float *part = a.parts + (size_t)gt * 2 * REC;
 
-  int lead_state = LEAD_NONE, trail_state = 0;
-  bool carry_open = false;
-  uint32_t carry_key = NOKEY;
-  float4 carV = splat(0.f), carA = splat(0.f);
-  float carw = 0.f;
+  uint32_t k[EPG];
+  bool val[EPG], tail[EPG];
+#pragma unroll
+  for (int j = 0; j < EPG; ++j) {
+    k[j] = c[j] >> bbits;
+    val[j] = c[j] != SENT;
+  }
+#pragma unroll
+  for (int j = 0; j < EPG; ++j) tail[j] = val[j] && (k[j] != (j + 1 < EPG ? k[j + 1] : knext));
 
-  if (__ballot(c != SENT) != 0ull) {
+  // ---- issue the loads: rows of the runs that end here (HBM / MALL), then S of every occurrence (L2) ----
+  RowRegs row[PREFETCH_ROWS ? EPG : 1];
+  if (PREFETCH_ROWS) {
 #pragma unroll
-    for (int p0 = 0; p0 < PASSES; p0 += GROUP) {
-      uint32_t ks[GROUP], kn[GROUP];
-      bool val[GROUP], tail[GROUP], upd[GROUP];
-      float4 cV[GROUP], cA[GROUP];
-      float cw[GROUP];
-      RowRegs row[GROUP];
-      // ---- issue every load of GROUP passes: run sums need S (L2), complete runs need their row (HBM / MALL) ----
-#pragma unroll
-      for (int g = 0; g < GROUP; ++g) {
-        const int e = (p0 + g) * SLOTS + slot;
-        const uint32_t cs = __shfl(c, e);
-        const uint32_t cnx = __shfl(c, (e + 1) & 63);
-        const uint32_t cn = (e + 1 < 64) ? cnx : nextc;
-        ks[g] = cs >> bbits;
-        kn[g] = cn >> bbits;
-        val[g] = cs != SENT;
-        tail[g] = val[g] && (kn[g] != ks[g]);
-        upd[g] = tail[g] && (ks[g] != prevkey);  // the run's head is in this tile too: complete here
-        cV[g] = splat(0.f);
-        cA[g] = splat(0.f);
-        cw[g] = 0.f;
-        row[g].v = splat(0.f);
-        row[g].z = splat(0.f);
-        row[g].n = splat(0.f);
-        row[g].fo = splat(0.f);
-        if (upd[g]) row[g] = load_row<LAYOUT>(a.rows + (row0 + ks[g]) * (size_t)a.stride, q, kp, a.zoff);
-        if (val[g]) {
-          const uint32_t b = cs & bmask;
-          const float4 S4 = *reinterpret_cast<const float4 *>(a.S + (size_t)b * kp + 4 * q);
-          const float x = a.xv ? a.xv[(size_t)b * a.F + f] : 1.f;
-          const float dzb = a.dz_bi ? a.dz_bi[b] : 0.f;
-          float4 G = splat(dzb);
-          if (HAS_GBI) G = G + *reinterpret_cast<const float4 *>(a.gbi + (size_t)b * kp + 4 * q);
-          const float4 xG = x * G;
-          cV[g] = xG * S4;
-          cA[g] = x * xG;
-          cw[g] = x * a.dz_first[b];
-        }
-      }
-      // ---- per pass: segmented scan over the slots, carry, row update / partial at run tails ----
-#pragma unroll
-      for (int g = 0; g < GROUP; ++g) {
-        const uint32_t k = ks[g];
-#pragma unroll
-        for (int off = 1; off < SLOTS; off <<= 1) {
-          const uint32_t ok = __shfl_up(k, off * LPR);
-          const float4 tV = shfl_up4(cV[g], off * LPR);
-          const float4 tA = shfl_up4(cA[g], off * LPR);
-          const float tw = __shfl_up(cw[g], off * LPR);
-          if (slot >= off && ok == k) {
-            cV[g] = cV[g] + tV;
-            cA[g] = cA[g] + tA;
-            cw[g] += tw;
-          }
-        }
-        if (carry_open && k == carry_key) {
-          cV[g] = cV[g] + carV;
-          cA[g] = cA[g] + carA;
-          cw[g] += carw;
-        }
-        if (upd[g]) {
-          update_row<LAYOUT, RULE>(a.rows + (row0 + k) * (size_t)a.stride, q, kp, a.zoff, row[g], cV[g], cA[g], cw[g], a.h);
-        } else if (tail[g]) {
-          store_part(part, q, kp, cV[g], cA[g], cw[g]);  // the run that came in from the previous tile ends here
-        }
-        if (__ballot(tail[g] && !upd[g]) != 0ull) lead_state = LEAD_CLOSES;
-        // carry out of the pass: the last slot, when its run continues
-        const bool open = __shfl((int)(val[g] && !tail[g]), LAST + q) != 0;
-        const uint32_t lk = __shfl(k, LAST + q);
-        const float4 lV = shfl4(cV[g], LAST + q);
-        const float4 lA = shfl4(cA[g], LAST + q);
-        const float lw = __shfl(cw[g], LAST);
-        carry_open = open;
-        carry_key = open ? lk : NOKEY;
-        carV = open ? lV : splat(0.f);
-        carA = open ? lA : splat(0.f);
-        carw = open ? lw : 0.f;
-      }
+    for (int j = 0; j < EPG; ++j) {
+      row[j].v = splat(0.f);
+      row[j].z = splat(0.f);
+      row[j].n = splat(0.f);
+      row[j].fo = splat(0.f);
+      if (tail[j] && k[j] != tile_prevkey)
+        row[j] = load_row<LAYOUT>(a.rows + (row0 + k[j]) * (size_t)a.stride, q, kp, a.zoff);
     }
-    if (carry_open) {  // the tile's last run continues in the next tile
-      if (carry_key == prevkey) {
-        lead_state = LEAD_THROUGH;  // the whole tile is one run, open at both ends
-        if (lane < LPR) store_part(part, q, kp, carV, carA, carw);
+  }
+  float4 cV[EPG];
+  CA cA[EPG];
+  float cw[EPG];
+#pragma unroll
+  for (int j = 0; j < EPG; ++j) {
+    cV[j] = splat(0.f);
+    cA[j].zero();
+    cw[j] = 0.f;
+    if (val[j]) {
+      const uint32_t b = c[j] & bmask;
+      const float4 S4 = *reinterpret_cast<const float4 *>(a.S + (size_t)b * kp + 4 * q);
+      const float x = a.xv ? a.xv[(size_t)b * a.F + f] : 1.f;
+      const float dzb = a.dz_bi ? a.dz_bi[b] : 0.f;
+      cw[j] = x * a.dz_first[b];
+      if constexpr (HAS_GBI) {
+        const float4 G = splat(dzb) + *reinterpret_cast<const float4 *>(a.gbi + (size_t)b * kp + 4 * q);
+        const float4 xG = x * G;
+        cV[j] = xG * S4;
+        cA[j].v = x * xG;
       } else {
-        trail_state = 1;
-        if (lane < LPR) store_part(part + REC, q, kp, carV, carA, carw);
+        const float xG = x * dzb;
+        cV[j] = xG * S4;
+        cA[j].v = x * xG;
       }
     }
+  }
+
+  // ---- pass 1: the sum of the group's last run, and whether the group lies inside one longer run ----
+  float4 tV = splat(0.f);
+  CA tA;
+  tA.zero();
+  float tw = 0.f;
+  bool uniform = true;
+#pragma unroll
+  for (int j = 0; j < EPG; ++j) {
+    if (j > 0 && k[j] != k[j - 1]) {
+      tV = splat(0.f);
+      tA.zero();
+      tw = 0.f;
+      uniform = false;
+    }
+    tV = tV + cV[j];
+    tA.add(cA[j]);
+    tw += cw[j];
+  }
+  const bool lead_open = val[0] && k[0] == kprev;
+  const bool trail_open = val[EPG - 1] && k[EPG - 1] == knext;
+  bool pass = uniform && lead_open && trail_open;
+  if (!trail_open) {
+    tV = splat(0.f);
+    tA.zero();
+    tw = 0.f;
+  }
+  // ---- segmented scan over the groups: carry_out(s) = v(s) + (pass(s) ? carry_out(s-1) : 0) ----
+#pragma unroll
+  for (int off = 1; off < SLOTS; off <<= 1) {
+    const float4 uV = shfl_up4(tV, off * LPR);
+    const CA uA = tA.up(off * LPR);
+    const float uw = __shfl_up(tw, off * LPR);
+    const bool up = __shfl_up((int)pass, off * LPR) != 0;
+    if (slot >= off) {
+      if (pass) {
+        tV = tV + uV;
+        tA.add(uA);
+        tw += uw;
+      }
+      pass = pass && up;
+    }
+  }
+  // carry into this group = carry out of the previous one
+  float4 accV = shfl_up4(tV, LPR);
+  CA accA = tA.up(LPR);
+  float accw = __shfl_up(tw, LPR);
+  if (slot == 0 || !lead_open) {
+    accV = splat(0.f);
+    accA.zero();
+    accw = 0.f;
+  }
+
+  // ---- pass 2: walk the occurrences again; at the tail of a run apply the update or leave a partial ----
+  bool closes = false;
+#pragma unroll
+  for (int j = 0; j < EPG; ++j) {
+    if (j > 0 && k[j] != k[j - 1]) {
+      accV = splat(0.f);
+      accA.zero();
+      accw = 0.f;
+    }
+    accV = accV + cV[j];
+    accA.add(cA[j]);
+    accw += cw[j];
+    if (tail[j]) {
+      if (k[j] != tile_prevkey) {
+        float *rp = a.rows + (row0 + k[j]) * (size_t)a.stride;
+        const RowRegs r = PREFETCH_ROWS ? row[PREFETCH_ROWS ? j : 0] : load_row<LAYOUT>(rp, q, kp, a.zoff);
+        update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, accV, accA.vec(), accw, a.h);
+      } else {
+        store_part(part, q, kp, accV, accA.vec(), accw);  // the run that came in from the previous tile ends here
+        closes = true;
+      }
+    }
+  }
+  // ---- the tile's last run continues in the next tile: its sum so far is the last group's carry-out ----
+  int lead_state = __ballot(closes) != 0ull ? LEAD_CLOSES : LEAD_NONE;
+  int trail_state = 0;
+  const bool tile_open = __shfl((int)trail_open, WAVE - 1) != 0;
+  if (tile_open) {
+    const bool through = __shfl((int)(k[EPG - 1] == tile_prevkey), WAVE - 1) != 0;
+    if (through) lead_state = LEAD_THROUGH;  // the whole tile is one run, open at both ends
+    else trail_state = 1;
+    if (slot == SLOTS - 1) store_part(part + (through ? 0 : REC), q, kp, tV, tA.vec(), tw);
   }
   if (lane == 0) {
     a.meta[(size_t)gt * 2] = lead_state;
@@ -715,9 +778,11 @@ int check_sort_geometry(const fmx_table_t *t, int B) {
   return FMX_OK;
 }
 
-// ---- workspace carving: [ sorted u32 F*Bp | meta i32 F*tiles*2 | parts f32 F*tiles*2*REC ], each 256-byte aligned ----
+// ---- workspace carving: [ sorted u32 F*Bp (x2: the online loop sorts batch t+1 while batch t is consumed) |
+//                          meta i32 F*tiles*2 | parts f32 F*tiles*2*REC ], each 256-byte aligned ----
 struct Workspace {
-  uint32_t *sorted;
+  uint32_t *sorted;   // buffer 0
+  uint32_t *sorted1;  // buffer 1
   int32_t *meta;
   float *parts;
   size_t bytes;
@@ -728,16 +793,46 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 Workspace carve(const fmx_table_t *t, int B, void *base) {
   const size_t F = (size_t)t->n_fields, Bp = (size_t)fmx_sorted_width(B), tiles = Bp >> 6;
   const size_t rec = 2 * (size_t)t->kp + 4;
-  const size_t o_meta = align_up(F * Bp * 4, 256);
+  const size_t o_sorted1 = align_up(F * Bp * 4, 256);
+  const size_t o_meta = 2 * o_sorted1;
   const size_t o_parts = o_meta + align_up(F * tiles * 2 * 4, 256);
   Workspace w;
   char *p = static_cast<char *>(base);
   w.sorted = reinterpret_cast<uint32_t *>(p);
+  w.sorted1 = reinterpret_cast<uint32_t *>(p + o_sorted1);
   w.meta = reinterpret_cast<int32_t *>(p + o_meta);
   w.parts = reinterpret_cast<float *>(p + o_parts);
   w.bytes = o_parts + align_up(F * tiles * 2 * rec * 4, 256);
   return w;
 }
+
+// ---- a library-owned side stream per device: the occurrence sort does not depend on the weights, so it runs beside
+//      the forward pass (fmx_fm_step) or one batch ahead (fmx_fm_stream).  Created on first use, never destroyed. ----
+struct Side {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, sorted[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+};
+
+Side *side_for_current_device() {
+  static std::mutex mu;
+  static Side sides[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  Side &sd = sides[dev];
+  if (!sd.stream) {
+    if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    bool ok = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) {
+      ok = hipEventCreateWithFlags(&sd.sorted[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&sd.consumed[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) return nullptr;
+  }
+  return &sd;
+}
+
+constexpr int OVERLAP_MIN_BATCH = 512;  // below this the extra event traffic costs more than the sort
 
 template <int LPR, int NPASS>
 void launch_forward_np(const FwdArgs &a, int layout, hipStream_t st) {
@@ -867,14 +962,15 @@ int forward_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32
   return check_launch("k_fm_forward");
 }
 
-int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const Workspace &w, const float *xv,
+int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const Workspace &w,
+                const uint32_t *sorted, const float *xv,
                 const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
                 const float *loss_b, float inv_b, float *loss_out, hipStream_t st, hipEvent_t mid) {
   UpdArgs a;
   a.rows = table->rows;
   a.foff = table->field_offsets;
   a.bias = table->bias;
-  a.sorted = w.sorted;
+  a.sorted = sorted;
   a.parts = w.parts;
   a.meta = w.meta;
   a.xv = xv;
@@ -984,7 +1080,8 @@ int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
   if (int rc = check_sort_geometry(table, B)) return rc;
   if (!aligned16(workspace) || !aligned16(S) || (gbi && !aligned16(gbi)))
     return fail(FMX_ERR_ALIGN, "workspace, S and gbi must be 16-byte aligned");
-  return update_impl(table, hyper, rule, carve(table, B, workspace), xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out,
+  const Workspace w = carve(table, B, workspace);
+  return update_impl(table, hyper, rule, w, w.sorted, xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out,
                      static_cast<hipStream_t>(stream), nullptr);
 }
 
@@ -995,9 +1092,20 @@ int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
   if (!idx || !y) return fail(FMX_ERR_ARG, "fmx_fm_step: idx and y are required");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const Workspace w = carve(table, B, workspace);
-  if (int rc = sort_impl(table, idx, B, w.sorted, fwd->error, st)) return rc;
-  if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
-  return update_impl(table, hyper, rule, w, xv, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b, loss_out, st, nullptr);
+  Side *sd = B >= OVERLAP_MIN_BATCH ? side_for_current_device() : nullptr;
+  if (sd) {  // sort beside the forward pass: fork -> {side: sort} || {main: forward} -> join -> update
+    (void)hipEventRecord(sd->fork, st);
+    (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
+    if (int rc = sort_impl(table, idx, B, w.sorted, fwd->error, sd->stream)) return rc;
+    (void)hipEventRecord(sd->sorted[0], sd->stream);
+    if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
+    (void)hipStreamWaitEvent(st, sd->sorted[0], 0);
+  } else {
+    if (int rc = sort_impl(table, idx, B, w.sorted, fwd->error, st)) return rc;
+    if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
+  }
+  return update_impl(table, hyper, rule, w, w.sorted, xv, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b, loss_out, st,
+                     nullptr);
 }
 
 int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
@@ -1009,44 +1117,74 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
   hipStream_t st = static_cast<hipStream_t>(stream);
   const Workspace w = carve(table, B, workspace);
   const size_t F = (size_t)table->n_fields;
-  const int n_ev = 5;
-  hipEvent_t *ev = nullptr;
-  if (kernel_ms) {  // timing mode: HIP events on the launch stream around every kernel
-    ev = new hipEvent_t[(size_t)n_steps * n_ev];
-    for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventCreate(&ev[i]);
-  }
+  uint32_t *const sorted[2] = {w.sorted, w.sorted1};
   int rc = FMX_OK;
+
+  if (!kernel_ms) {
+    // production path: batch s+1 is sorted on the side stream while batch s runs forward / update on `stream`
+    Side *sd = (B >= OVERLAP_MIN_BATCH && n_steps > 0) ? side_for_current_device() : nullptr;
+    if (sd) {
+      (void)hipEventRecord(sd->fork, st);
+      (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
+      rc = sort_impl(table, idx_pool, B, sorted[0], fwd->error, sd->stream);
+      (void)hipEventRecord(sd->sorted[0], sd->stream);
+    }
+    for (int s = 0; s < n_steps && rc == FMX_OK; ++s) {
+      const int j = s % n_pool, cur = s & 1, nxt = cur ^ 1;
+      const int32_t *idx = idx_pool + (size_t)j * B * F;
+      const float *y = y_pool + (size_t)j * B;
+      if (sd) {
+        if (s + 1 < n_steps) {
+          if (s >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[nxt], 0);  // update(s-1) is done with buffer nxt
+          rc = sort_impl(table, idx_pool + (size_t)((s + 1) % n_pool) * B * F, B, sorted[nxt], fwd->error, sd->stream);
+          (void)hipEventRecord(sd->sorted[nxt], sd->stream);
+        }
+      } else {
+        rc = sort_impl(table, idx, B, sorted[cur], fwd->error, st);
+      }
+      if (rc == FMX_OK) rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
+      if (sd) (void)hipStreamWaitEvent(st, sd->sorted[cur], 0);
+      if (rc == FMX_OK)
+        rc = update_impl(table, hyper, rule, w, sorted[cur], nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
+                         loss_out ? loss_out + s : nullptr, st, nullptr);
+      if (sd) (void)hipEventRecord(sd->consumed[cur], st);
+    }
+    return rc;
+  }
+
+  // timing mode: everything on `stream`, HIP events around every kernel
+  const int n_ev = 5;
+  hipEvent_t *ev = new hipEvent_t[(size_t)n_steps * n_ev];
+  for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventCreate(&ev[i]);
   for (int s = 0; s < n_steps && rc == FMX_OK; ++s) {
     const int j = s % n_pool;
     const int32_t *idx = idx_pool + (size_t)j * B * F;
     const float *y = y_pool + (size_t)j * B;
-    hipEvent_t *e = ev ? ev + (size_t)s * n_ev : nullptr;
-    if (e) (void)hipEventRecord(e[0], st);
+    hipEvent_t *e = ev + (size_t)s * n_ev;
+    (void)hipEventRecord(e[0], st);
     rc = sort_impl(table, idx, B, w.sorted, fwd->error, st);
-    if (e) (void)hipEventRecord(e[1], st);
+    (void)hipEventRecord(e[1], st);
     if (rc == FMX_OK) rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
-    if (e) (void)hipEventRecord(e[2], st);
+    (void)hipEventRecord(e[2], st);
     if (rc == FMX_OK)
-      rc = update_impl(table, hyper, rule, w, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                       loss_out ? loss_out + s : nullptr, st, e ? e[3] : nullptr);
-    if (e) (void)hipEventRecord(e[4], st);
+      rc = update_impl(table, hyper, rule, w, w.sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
+                       loss_out ? loss_out + s : nullptr, st, e[3]);
+    (void)hipEventRecord(e[4], st);
   }
-  if (ev) {
-    (void)hipStreamSynchronize(st);
-    for (int k = 0; k < 4; ++k) kernel_ms[k] = 0.f;
-    if (rc == FMX_OK) {
-      for (int s = 0; s < n_steps; ++s) {
-        hipEvent_t *e = ev + (size_t)s * n_ev;
-        for (int k = 0; k < 4; ++k) {
-          float ms = 0.f;
-          (void)hipEventElapsedTime(&ms, e[k], e[k + 1]);
-          kernel_ms[k] += ms;
-        }
+  (void)hipStreamSynchronize(st);
+  for (int k = 0; k < 4; ++k) kernel_ms[k] = 0.f;
+  if (rc == FMX_OK) {
+    for (int s = 0; s < n_steps; ++s) {
+      hipEvent_t *e = ev + (size_t)s * n_ev;
+      for (int k = 0; k < 4; ++k) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e[k], e[k + 1]);
+        kernel_ms[k] += ms;
       }
     }
-    for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventDestroy(ev[i]);
-    delete[] ev;
   }
+  for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
   return rc;
 }
 
