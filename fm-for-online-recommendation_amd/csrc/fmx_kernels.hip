@@ -21,9 +21,11 @@
 // Everything is HBM / cache-line bound integer+fp32 work; there is no GEMM here and no MFMA.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -127,27 +129,56 @@ struct SortArgs {
   int32_t B, F, Bp, bbits;
 };
 
+// lane ^ M exchanges without the LDS crossbar (ds_bpermute made the sort LDS-pipe bound): DPP for M = 1, 2, 4, 8,
+// v_permlane16/32_swap for M = 16, 32.
+template <int M>
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v, int lane) {
+  if constexpr (M == 1) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  } else if constexpr (M == 2) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  } else if constexpr (M == 4) {
+    const int t = __builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);     // row_half_mirror: i -> 7 - i
+    return (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x1B, 0xF, 0xF, true);         // quad_perm [3,2,1,0]: together i ^ 4
+  } else if constexpr (M == 8) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  } else if constexpr (M == 16) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // {[r0,r0,r2,r2], [r1,r1,r3,r3]}
+    return (lane & 16) ? sw[0] : sw[1];
+  } else {
+    const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // {[lo,lo], [hi,hi]}
+    return (lane & 32) ? sw[0] : sw[1];
+  }
+}
+
 // Bitonic network on N = Bp composites held E per thread in a blocked layout (element i = tid * E + r):
 //   partner distance j <  E        in-thread compare-exchange
-//   E <= j < 64 E                  partner in another lane of the wave: __shfl_xor
+//   E <= j < 64 E                  partner in another lane of the wave: xor_lane<j / E>
 //   j >= 64 E                      partner in another wave: through LDS
+template <int E, int LJ>
+__device__ __forceinline__ void bitonic_lane_stage(uint32_t (&v)[E], int i0, int lane, int k) {
+  const bool lower = (lane & LJ) == 0;
+  const bool up = (i0 & k) == 0;  // (i & k) is the same for all r because k > j >= E
+  const bool take_min = lower == up;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const uint32_t o = xor_lane<LJ>(v[r], lane);
+    const uint32_t lo = v[r] < o ? v[r] : o, hi = v[r] < o ? o : v[r];
+    v[r] = take_min ? lo : hi;
+  }
+}
+
 template <int E>
 __device__ __forceinline__ void bitonic_local(uint32_t (&v)[E], int tid, int k, int jmax) {
   // stages j = jmax, jmax/2, ..., 1 of merge level k, all of which stay inside one wave
   const int i0 = tid * E;
   const int lane = tid & 63;
-#pragma unroll 1
-  for (int j = jmax; j >= E && j > 0; j >>= 1) {
-    const int lj = j / E;  // lane distance
-    const bool lower = (lane & lj) == 0;
-    const bool up = (i0 & k) == 0;  // (i & k) is the same for all r because k > j >= E
-    const bool take_min = lower == up;
-#pragma unroll
-    for (int r = 0; r < E; ++r) {
-      const uint32_t o = __shfl_xor(v[r], lj);
-      v[r] = take_min ? (v[r] < o ? v[r] : o) : (v[r] > o ? v[r] : o);
-    }
-  }
+  if (jmax >= 32 * E) bitonic_lane_stage<E, 32>(v, i0, lane, k);
+  if (jmax >= 16 * E) bitonic_lane_stage<E, 16>(v, i0, lane, k);
+  if (jmax >= 8 * E) bitonic_lane_stage<E, 8>(v, i0, lane, k);
+  if (jmax >= 4 * E) bitonic_lane_stage<E, 4>(v, i0, lane, k);
+  if (jmax >= 2 * E) bitonic_lane_stage<E, 2>(v, i0, lane, k);
+  if (jmax >= E) bitonic_lane_stage<E, 1>(v, i0, lane, k);
 #pragma unroll
   for (int j = E / 2; j > 0; j >>= 1) {
     if (j <= jmax) {
@@ -234,7 +265,7 @@ __global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
   constexpr int SLOTS = WAVE / LPR;
   constexpr int NP = NPASS > 0 ? NPASS : 1;
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= a.B) return;  // wave-uniform
   const int slot = lane / LPR, q = lane % LPR;
   const int kp = LPR * 4;
@@ -357,6 +388,7 @@ struct UpdArgs {
   const float *gbi;
   const float *loss_b;
   float *loss_out;
+  int32_t *step_counter;  // null: loss_out[0]; else loss_out[*step_counter], then *step_counter += 1
   fmx_hyper_t h;
   int32_t B, F, Bp, bbits, kp, stride, zoff;
   float inv_b;
@@ -365,13 +397,21 @@ struct UpdArgs {
 // tile meta states
 constexpr int LEAD_NONE = 0, LEAD_CLOSES = 1, LEAD_THROUGH = 2;
 
-// deterministic block reduction of src[0..n) by 256 threads (strided partials, then an LDS tree)
-__device__ float block_sum_256(const float *src, int n, float *sm) {
+// deterministic block reduction of src[0..n): every thread sums a strided set of 16-byte groups (all loads of a thread
+// are independent and issued together), then an LDS tree.  The order depends only on (n, blockDim).
+__device__ float block_sum(const float *src, int n, float *sm) {
   float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) acc += src[i];
+  const int n4 = n >> 2;
+  const float4 *src4 = reinterpret_cast<const float4 *>(src);
+#pragma unroll 4
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+    const float4 v = src4[i];
+    acc += (v.x + v.y) + (v.z + v.w);
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += src[i];
   sm[threadIdx.x] = acc;
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
+  for (int w = blockDim.x >> 1; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
     __syncthreads();
   }
@@ -383,9 +423,9 @@ __device__ float block_sum_256(const float *src, int n, float *sm) {
 template <int LAYOUT, int RULE>
 __device__ void bias_and_loss(const UpdArgs &a) {
   __shared__ float sm[256];
-  const float db = block_sum_256(a.dz_first, a.B, sm);
+  const float db = block_sum(a.dz_first, a.B, sm);
   float ls = 0.f;
-  if (a.loss_b && a.loss_out) ls = block_sum_256(a.loss_b, a.B, sm);
+  if (a.loss_b && a.loss_out) ls = block_sum(a.loss_b, a.B, sm);
   if (threadIdx.x == 0) {
     if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
       a.bias[0] = apply_rule<RULE>(a.bias[0], db, a.h);
@@ -396,7 +436,14 @@ __device__ void bias_and_loss(const UpdArgs &a) {
       a.bias[0] = z;
       a.bias[1] = n;
     }
-    if (a.loss_b && a.loss_out) a.loss_out[0] = ls * a.inv_b;
+    if (a.loss_b && a.loss_out) {
+      int i = 0;
+      if (a.step_counter) {
+        i = *a.step_counter;
+        *a.step_counter = i + 1;
+      }
+      a.loss_out[i] = ls * a.inv_b;
+    }
   }
 }
 
@@ -488,7 +535,7 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   constexpr int REC = 2 * LPR * 4 + 4;
   constexpr bool PREFETCH_ROWS = EPG <= 4;
   using CA = CoefA<HAS_GBI>;
-  if (blockIdx.x == gridDim.x - 1) {  // the last block owns the bias and the loss reduction
+  if (blockIdx.x == 0) {  // the first block (dispatched first) owns the bias and the loss reduction
     bias_and_loss<LAYOUT, RULE>(a);
     return;
   }
@@ -496,7 +543,7 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   const int slot = lane / LPR, q = lane % LPR;
   const int kp = LPR * 4;
   const int tiles_per_field = a.Bp >> 6;
-  const int gt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int gt = (blockIdx.x - 1) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (gt >= a.F * tiles_per_field) return;
   const int f = gt / tiles_per_field;
   const int base = (gt - f * tiles_per_field) << 6;
@@ -666,7 +713,7 @@ __global__ __launch_bounds__(256) void k_fm_fixup(UpdArgs a) {
   const int slot = lane / LPR, q = lane % LPR;
   const int kp = LPR * 4;
   const int tiles_per_field = a.Bp >> 6;
-  const int gt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (gt >= a.F * tiles_per_field) return;
   if (a.meta[(size_t)gt * 2 + 1] != 1) return;  // wave-uniform
   const int f = gt / tiles_per_field;
@@ -778,12 +825,39 @@ int check_sort_geometry(const fmx_table_t *t, int B) {
   return FMX_OK;
 }
 
+// ---- launch geometry knobs (waves per workgroup), overridable from the environment for experiments ----
+struct Tune {
+  int wpb_fwd = 4, wpb_upd = 4;
+  int use_graph = 0;  // FMX_GRAPH=1 replays one pool pass as a hipGraph (measured slower on ROCm 7.2: the graph
+                      // executor serialises the sort branch; kept for re-measurement)
+  int sort_e = 0;     // FMX_SORT_E: elements per thread of the bitonic sort (0 = default)
+  int ext_events = 0; // FMX_EXT_EVENTS=1: completion events ride on the launches (hipExtLaunchKernel); slower on the host
+  int sort_cus = 0;   // FMX_SORT_CUS=n: reserve n CUs for the side-stream sort (CU-masked library streams)
+};
+const Tune &tune() {
+  static const Tune t = [] {
+    Tune x;
+    if (const char *e = getenv("FMX_WPB_FWD")) x.wpb_fwd = atoi(e);
+    if (const char *e = getenv("FMX_WPB_UPD")) x.wpb_upd = atoi(e);
+    if (const char *e = getenv("FMX_GRAPH")) x.use_graph = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("FMX_SORT_E")) x.sort_e = atoi(e);
+    if (const char *e = getenv("FMX_EXT_EVENTS")) x.ext_events = atoi(e);
+    if (const char *e = getenv("FMX_SORT_CUS")) x.sort_cus = atoi(e);
+    auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
+    if (!ok(x.wpb_fwd)) x.wpb_fwd = 4;
+    if (!ok(x.wpb_upd)) x.wpb_upd = 4;
+    return x;
+  }();
+  return t;
+}
+
 // ---- workspace carving: [ sorted u32 F*Bp (x2: the online loop sorts batch t+1 while batch t is consumed) |
 //                          meta i32 F*tiles*2 | parts f32 F*tiles*2*REC ], each 256-byte aligned ----
 struct Workspace {
   uint32_t *sorted;   // buffer 0
   uint32_t *sorted1;  // buffer 1
   int32_t *meta;
+  int32_t *counter;  // step counter of fmx_fm_stream (one int32 in its own 256-byte slot)
   float *parts;
   size_t bytes;
 };
@@ -795,12 +869,14 @@ Workspace carve(const fmx_table_t *t, int B, void *base) {
   const size_t rec = 2 * (size_t)t->kp + 4;
   const size_t o_sorted1 = align_up(F * Bp * 4, 256);
   const size_t o_meta = 2 * o_sorted1;
-  const size_t o_parts = o_meta + align_up(F * tiles * 2 * 4, 256);
+  const size_t o_counter = o_meta + align_up(F * tiles * 2 * 4, 256);
+  const size_t o_parts = o_counter + 256;
   Workspace w;
   char *p = static_cast<char *>(base);
   w.sorted = reinterpret_cast<uint32_t *>(p);
   w.sorted1 = reinterpret_cast<uint32_t *>(p + o_sorted1);
   w.meta = reinterpret_cast<int32_t *>(p + o_meta);
+  w.counter = reinterpret_cast<int32_t *>(p + o_counter);
   w.parts = reinterpret_cast<float *>(p + o_parts);
   w.bytes = o_parts + align_up(F * tiles * 2 * rec * 4, 256);
   return w;
@@ -809,8 +885,11 @@ Workspace carve(const fmx_table_t *t, int B, void *base) {
 // ---- a library-owned side stream per device: the occurrence sort does not depend on the weights, so it runs beside
 //      the forward pass (fmx_fm_step) or one batch ahead (fmx_fm_stream).  Created on first use, never destroyed. ----
 struct Side {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;  // the sort runs here
+  hipStream_t main = nullptr;    // stands in for the caller's stream when that is the legacy default stream, which
+                                 // cannot be captured into a hipGraph
   hipEvent_t fork = nullptr, sorted[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  hipEvent_t user_fork = nullptr, user_join = nullptr;
 };
 
 Side *side_for_current_device() {
@@ -821,8 +900,28 @@ Side *side_for_current_device() {
   std::lock_guard<std::mutex> lock(mu);
   Side &sd = sides[dev];
   if (!sd.stream) {
-    if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    bool ok = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
+    // Optional CU partition (FMX_SORT_CUS=n): the sort's n workgroup-sized CUs are taken out of the stand-in main
+    // stream's mask, so a sort workgroup never shares a CU with (and never slows down) forward / update workgroups.
+    const int n_sort = tune().sort_cus;
+    hipDeviceProp_t prop;
+    bool masked = false;
+    if (n_sort > 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > n_sort) {
+      const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
+      uint32_t m_side[16] = {0}, m_main[16] = {0};
+      for (int c = 0; c < n_cu && words <= 16; ++c) {
+        if (c < n_sort) m_side[c / 32] |= 1u << (c % 32);
+        else m_main[c / 32] |= 1u << (c % 32);
+      }
+      masked = words <= 16 && hipExtStreamCreateWithCUMask(&sd.stream, words, m_side) == hipSuccess &&
+               hipExtStreamCreateWithCUMask(&sd.main, words, m_main) == hipSuccess;
+    }
+    if (!masked) {
+      if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+      if (hipStreamCreateWithFlags(&sd.main, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    }
+    bool ok = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&sd.user_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&sd.user_join, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i) {
       ok = hipEventCreateWithFlags(&sd.sorted[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&sd.consumed[i], hipEventDisableTiming) == hipSuccess;
@@ -832,11 +931,32 @@ Side *side_for_current_device() {
   return &sd;
 }
 
+// ---- one cached hipGraph of the online loop per device, keyed by every argument baked into its kernel nodes ----
+struct GraphKey {
+  fmx_table_t table;
+  fmx_hyper_t hyper;
+  fmx_fwd_out_t fwd;
+  const void *idx_pool, *y_pool, *workspace, *loss_out, *stream;
+  int32_t rule, loss_kind, n_pool, B;
+  float inv_b;
+};
+struct GraphSlot {
+  GraphKey key;
+  hipGraphExec_t exec = nullptr;
+};
+GraphSlot *graph_slot_for_current_device() {
+  static GraphSlot slots[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return &slots[dev];
+}
+
 constexpr int OVERLAP_MIN_BATCH = 512;  // below this the extra event traffic costs more than the sort
 
 template <int LPR, int NPASS>
 void launch_forward_np(const FwdArgs &a, int layout, hipStream_t st) {
-  const dim3 grid((a.B + 3) / 4), block(256);
+  const int wpb = tune().wpb_fwd;
+  const dim3 grid((a.B + wpb - 1) / wpb), block(64 * wpb);
   if (layout == FMX_LAYOUT_WEIGHTS) hipLaunchKernelGGL((k_fm_forward<LPR, FMX_LAYOUT_WEIGHTS, NPASS>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_fm_forward<LPR, FMX_LAYOUT_FTRL, NPASS>), grid, block, 0, st, a);
 }
@@ -857,7 +977,8 @@ void launch_forward(const FwdArgs &a, int layout, hipStream_t st) {
 template <int LPR, bool HAS_GBI>
 void launch_update(const UpdArgs &a, int rule, hipStream_t st) {
   const int tiles = a.F * (a.Bp >> 6);
-  const dim3 grid((tiles + 3) / 4 + 1), block(256);
+  const int wpb = tune().wpb_upd;
+  const dim3 grid((tiles + wpb - 1) / wpb + 1), block(64 * wpb);
   switch (rule) {
     case FMX_RULE_SIGNADAM:
       hipLaunchKernelGGL((k_fm_update<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, HAS_GBI>), grid, block, 0, st, a);
@@ -871,38 +992,58 @@ void launch_update(const UpdArgs &a, int rule, hipStream_t st) {
   }
 }
 
+template <int LPR, int LAYOUT, int RULE>
+void launch_fixup_k(const UpdArgs &a, dim3 grid, dim3 block, hipStream_t st, hipEvent_t stop) {
+  if (stop) hipExtLaunchKernelGGL((k_fm_fixup<LPR, LAYOUT, RULE>), grid, block, 0, st, nullptr, stop, 0, a);
+  else hipLaunchKernelGGL((k_fm_fixup<LPR, LAYOUT, RULE>), grid, block, 0, st, a);
+}
+
 template <int LPR>
-void launch_fixup(const UpdArgs &a, int rule, hipStream_t st) {
+void launch_fixup(const UpdArgs &a, int rule, hipStream_t st, hipEvent_t stop) {
   const int tiles = a.F * (a.Bp >> 6);
-  const dim3 grid((tiles + 3) / 4), block(256);
+  const int wpb = tune().wpb_upd;
+  const dim3 grid((tiles + wpb - 1) / wpb), block(64 * wpb);
   switch (rule) {
-    case FMX_RULE_SIGNADAM:
-      hipLaunchKernelGGL((k_fm_fixup<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM>), grid, block, 0, st, a);
-      break;
-    case FMX_RULE_SGD:
-      hipLaunchKernelGGL((k_fm_fixup<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD>), grid, block, 0, st, a);
-      break;
-    default:
-      hipLaunchKernelGGL((k_fm_fixup<LPR, FMX_LAYOUT_FTRL, FMX_RULE_FTRL>), grid, block, 0, st, a);
-      break;
+    case FMX_RULE_SIGNADAM: launch_fixup_k<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM>(a, grid, block, st, stop); break;
+    case FMX_RULE_SGD: launch_fixup_k<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD>(a, grid, block, st, stop); break;
+    default: launch_fixup_k<LPR, FMX_LAYOUT_FTRL, FMX_RULE_FTRL>(a, grid, block, st, stop); break;
   }
 }
 
 template <int LPR>
-void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st, hipEvent_t mid) {
+void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st, hipEvent_t mid, hipEvent_t stop) {
   if (has_gbi) launch_update<LPR, true>(a, rule, st);
   else launch_update<LPR, false>(a, rule, st);
   if (mid) (void)hipEventRecord(mid, st);
-  launch_fixup<LPR>(a, rule, st);
+  launch_fixup<LPR>(a, rule, st, stop);
 }
 
 template <int E>
-void launch_sort(const SortArgs &a, hipStream_t st) {
+void launch_sort(const SortArgs &a, hipStream_t st, hipEvent_t stop) {
   const int threads = a.Bp / E;
-  hipLaunchKernelGGL((k_sort_occ<E>), dim3(a.F), dim3(threads), (size_t)a.Bp * sizeof(uint32_t), st, a);
+  if (stop)  // the completion event rides on the launch packet: one runtime call instead of launch + hipEventRecord
+    hipExtLaunchKernelGGL((k_sort_occ<E>), dim3(a.F), dim3(threads), (uint32_t)(a.Bp * sizeof(uint32_t)), st, nullptr, stop, 0, a);
+  else
+    hipLaunchKernelGGL((k_sort_occ<E>), dim3(a.F), dim3(threads), (size_t)a.Bp * sizeof(uint32_t), st, a);
 }
 
-int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t *sorted, int32_t *error, hipStream_t st) {
+int prepare_sort(int B) {
+  if ((size_t)fmx_sorted_width(B) * 4 <= 64 * 1024) return FMX_OK;
+  static std::mutex mu;
+  static bool raised = false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<8>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<16>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<32>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+    if (e != hipSuccess) return fail(FMX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    raised = true;
+  }
+  return FMX_OK;
+}
+
+int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t *sorted, int32_t *error, hipStream_t st,
+              hipEvent_t stop = nullptr) {
   SortArgs a;
   a.idx = idx;
   a.foff = table->field_offsets;
@@ -912,24 +1053,19 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
   a.F = table->n_fields;
   a.Bp = fmx_sorted_width(B);
   a.bbits = fmx_sorted_bbits(B);
-  if ((size_t)a.Bp * 4 > 64 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      hipError_t e = hipSuccess;
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<8>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<16>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<32>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
-      if (e != hipSuccess) return fail(FMX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-      raised = true;
-    }
-  }
+  if (int rc = prepare_sort(B)) return rc;
   // E elements per thread, Bp / E threads (a multiple of 64, at most 1024)
-  if (a.Bp <= 64) launch_sort<1>(a, st);
-  else if (a.Bp <= 128) launch_sort<2>(a, st);
-  else if (a.Bp <= 4096) launch_sort<4>(a, st);
-  else if (a.Bp <= 8192) launch_sort<8>(a, st);
-  else if (a.Bp <= 16384) launch_sort<16>(a, st);
-  else launch_sort<32>(a, st);
+  int E = a.Bp <= 64 ? 1 : a.Bp <= 128 ? 2 : a.Bp <= 4096 ? 4 : a.Bp <= 8192 ? 8 : a.Bp <= 16384 ? 16 : 32;
+  const int want = tune().sort_e;
+  if (want > E && want <= 32 && (want & (want - 1)) == 0 && a.Bp / want >= 64) E = want;
+  switch (E) {
+    case 1: launch_sort<1>(a, st, stop); break;
+    case 2: launch_sort<2>(a, st, stop); break;
+    case 4: launch_sort<4>(a, st, stop); break;
+    case 8: launch_sort<8>(a, st, stop); break;
+    case 16: launch_sort<16>(a, st, stop); break;
+    default: launch_sort<32>(a, st, stop); break;
+  }
   return check_launch("k_sort_occ");
 }
 
@@ -965,7 +1101,8 @@ int forward_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32
 int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const Workspace &w,
                 const uint32_t *sorted, const float *xv,
                 const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
-                const float *loss_b, float inv_b, float *loss_out, hipStream_t st, hipEvent_t mid) {
+                const float *loss_b, float inv_b, float *loss_out, hipStream_t st, hipEvent_t mid,
+                int32_t *step_counter = nullptr, hipEvent_t stop = nullptr) {
   UpdArgs a;
   a.rows = table->rows;
   a.foff = table->field_offsets;
@@ -980,6 +1117,7 @@ int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
   a.gbi = gbi;
   a.loss_b = loss_b;
   a.loss_out = loss_out;
+  a.step_counter = step_counter;
   a.h = *hyper;
   a.B = B;
   a.F = table->n_fields;
@@ -991,11 +1129,11 @@ int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
   a.h.alpha = 1.0f / hyper->alpha;  // the kernels multiply by 1/alpha
   a.inv_b = inv_b;
   switch (lpr_of(table->kp)) {
-    case 1: launch_update_pair<1>(a, rule, gbi != nullptr, st, mid); break;
-    case 2: launch_update_pair<2>(a, rule, gbi != nullptr, st, mid); break;
-    case 4: launch_update_pair<4>(a, rule, gbi != nullptr, st, mid); break;
-    case 8: launch_update_pair<8>(a, rule, gbi != nullptr, st, mid); break;
-    default: launch_update_pair<16>(a, rule, gbi != nullptr, st, mid); break;
+    case 1: launch_update_pair<1>(a, rule, gbi != nullptr, st, mid, stop); break;
+    case 2: launch_update_pair<2>(a, rule, gbi != nullptr, st, mid, stop); break;
+    case 4: launch_update_pair<4>(a, rule, gbi != nullptr, st, mid, stop); break;
+    case 8: launch_update_pair<8>(a, rule, gbi != nullptr, st, mid, stop); break;
+    default: launch_update_pair<16>(a, rule, gbi != nullptr, st, mid, stop); break;
   }
   return check_launch("k_fm_update / k_fm_fixup");
 }
@@ -1020,7 +1158,8 @@ int check_step_args(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t 
   if (!hyper || !workspace) return fail(FMX_ERR_ARG, "null hyper / workspace");
   if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
   if (!fwd || !fwd->S || !fwd->dz || !fwd->loss) return fail(FMX_ERR_ARG, "fwd->S, fwd->loss, fwd->dz are required");
-  if (!aligned16(fwd->S)) return fail(FMX_ERR_ALIGN, "S must be 16-byte aligned");
+  if (!aligned16(fwd->S) || !aligned16(fwd->dz) || !aligned16(fwd->loss))
+    return fail(FMX_ERR_ALIGN, "fwd->S, fwd->dz and fwd->loss must be 16-byte aligned");
   if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "a step needs a loss");
   return FMX_OK;
 }
@@ -1078,8 +1217,8 @@ int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
   if (!hyper || !workspace || !S || !dz_first) return fail(FMX_ERR_ARG, "fmx_fm_update: null argument");
   if (!dz_bi && !gbi) return fail(FMX_ERR_ARG, "fmx_fm_update: one of dz_bi / gbi is required");
   if (int rc = check_sort_geometry(table, B)) return rc;
-  if (!aligned16(workspace) || !aligned16(S) || (gbi && !aligned16(gbi)))
-    return fail(FMX_ERR_ALIGN, "workspace, S and gbi must be 16-byte aligned");
+  if (!aligned16(workspace) || !aligned16(S) || (gbi && !aligned16(gbi)) || !aligned16(dz_first) || (loss_b && !aligned16(loss_b)))
+    return fail(FMX_ERR_ALIGN, "workspace, S, gbi, dz_first and loss_b must be 16-byte aligned");
   const Workspace w = carve(table, B, workspace);
   return update_impl(table, hyper, rule, w, w.sorted, xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out,
                      static_cast<hipStream_t>(stream), nullptr);
@@ -1121,35 +1260,105 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
   int rc = FMX_OK;
 
   if (!kernel_ms) {
-    // production path: batch s+1 is sorted on the side stream while batch s runs forward / update on `stream`
+    // production path.  Batch s+1 is sorted on the side stream while batch s runs forward / update on `stream`.
+    // Optionally (FMX_GRAPH=1) one pass over the pool (n_pool steps) is captured into a hipGraph and replayed.
     Side *sd = (B >= OVERLAP_MIN_BATCH && n_steps > 0) ? side_for_current_device() : nullptr;
-    if (sd) {
-      (void)hipEventRecord(sd->fork, st);
-      (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
-      rc = sort_impl(table, idx_pool, B, sorted[0], fwd->error, sd->stream);
-      (void)hipEventRecord(sd->sorted[0], sd->stream);
+    hipStream_t user = st;
+    const bool detour = sd && st == nullptr;  // the legacy default stream cannot be captured: detour through sd->main
+    if (detour) {
+      (void)hipEventRecord(sd->user_fork, user);
+      st = sd->main;
+      (void)hipStreamWaitEvent(st, sd->user_fork, 0);
     }
-    for (int s = 0; s < n_steps && rc == FMX_OK; ++s) {
-      const int j = s % n_pool, cur = s & 1, nxt = cur ^ 1;
-      const int32_t *idx = idx_pool + (size_t)j * B * F;
-      const float *y = y_pool + (size_t)j * B;
-      if (sd) {
-        if (s + 1 < n_steps) {
-          if (s >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[nxt], 0);  // update(s-1) is done with buffer nxt
-          rc = sort_impl(table, idx_pool + (size_t)((s + 1) % n_pool) * B * F, B, sorted[nxt], fwd->error, sd->stream);
-          (void)hipEventRecord(sd->sorted[nxt], sd->stream);
-        }
-      } else {
-        rc = sort_impl(table, idx, B, sorted[cur], fwd->error, st);
+    auto rejoin = [&](int r) -> int {
+      if (detour) {
+        (void)hipEventRecord(sd->user_join, st);
+        (void)hipStreamWaitEvent(user, sd->user_join, 0);
       }
-      if (rc == FMX_OK) rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
-      if (sd) (void)hipStreamWaitEvent(st, sd->sorted[cur], 0);
-      if (rc == FMX_OK)
-        rc = update_impl(table, hyper, rule, w, sorted[cur], nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                         loss_out ? loss_out + s : nullptr, st, nullptr);
-      if (sd) (void)hipEventRecord(sd->consumed[cur], st);
+      return r;
+    };
+    (void)hipMemsetAsync(w.counter, 0, sizeof(int32_t), st);
+    const bool ext = tune().ext_events != 0;
+    auto enqueue = [&](int first, int count) -> int {
+      int r = FMX_OK;
+      if (count <= 0) return r;
+      if (sd) {
+        (void)hipEventRecord(sd->fork, st);
+        (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
+        r = sort_impl(table, idx_pool + (size_t)(first % n_pool) * B * F, B, sorted[0], fwd->error, sd->stream);
+        (void)hipEventRecord(sd->sorted[0], sd->stream);
+      }
+      for (int s = 0; s < count && r == FMX_OK; ++s) {
+        const int j = (first + s) % n_pool, cur = s & 1, nxt = cur ^ 1;
+        const int32_t *idx = idx_pool + (size_t)j * B * F;
+        const float *y = y_pool + (size_t)j * B;
+        if (sd) {
+          if (s + 1 < count) {
+            if (s >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[nxt], 0);  // update(s-1) is done with buffer nxt
+            r = sort_impl(table, idx_pool + (size_t)((first + s + 1) % n_pool) * B * F, B, sorted[nxt], fwd->error, sd->stream,
+                          ext ? sd->sorted[nxt] : nullptr);
+            if (!ext) (void)hipEventRecord(sd->sorted[nxt], sd->stream);
+          }
+        } else {
+          r = sort_impl(table, idx, B, sorted[cur], fwd->error, st);
+        }
+        if (r == FMX_OK) r = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
+        if (sd) (void)hipStreamWaitEvent(st, sd->sorted[cur], 0);
+        if (r == FMX_OK)
+          r = update_impl(table, hyper, rule, w, sorted[cur], nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
+                          loss_out, st, nullptr, loss_out ? w.counter : nullptr, (sd && ext) ? sd->consumed[cur] : nullptr);
+        if (sd && !ext) (void)hipEventRecord(sd->consumed[cur], st);
+      }
+      return r;
+    };
+    const int n_graph = (sd && tune().use_graph) ? n_steps / n_pool : 0;
+    if (n_graph > 0) {
+      GraphKey key{};
+      key.table = *table;
+      key.hyper = *hyper;
+      key.fwd = *fwd;
+      key.idx_pool = idx_pool;
+      key.y_pool = y_pool;
+      key.workspace = workspace;
+      key.loss_out = loss_out;
+      key.stream = st;  // (sd->main when detouring)
+      key.rule = rule;
+      key.loss_kind = loss_kind;
+      key.n_pool = n_pool;
+      key.B = B;
+      key.inv_b = inv_b;
+      GraphSlot *slot = graph_slot_for_current_device();
+      if (slot && !(slot->exec && memcmp(&slot->key, &key, sizeof(key)) == 0)) {
+        if (slot->exec) {
+          (void)hipGraphExecDestroy(slot->exec);
+          slot->exec = nullptr;
+        }
+        if (int r = prepare_sort(B)) return rejoin(r);  // k_sort_occ raises its LDS limit on first use: not inside a capture
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+          rc = enqueue(0, n_pool);
+          e = hipStreamEndCapture(st, &graph);
+        }
+        if (e == hipSuccess && rc == FMX_OK) e = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess || rc != FMX_OK) {
+          slot->exec = nullptr;
+          (void)hipGetLastError();
+          if (rc != FMX_OK) return rejoin(rc);
+          return rejoin(fail(FMX_ERR_LAUNCH, "hipGraph capture of the online loop failed: %s", hipGetErrorString(e)));
+        }
+        slot->key = key;
+      }
+      if (slot && slot->exec) {
+        for (int g = 0; g < n_graph; ++g) {
+          hipError_t e = hipGraphLaunch(slot->exec, st);
+          if (e != hipSuccess) return rejoin(fail(FMX_ERR_LAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e)));
+        }
+        return rejoin(enqueue(n_graph * n_pool, n_steps - n_graph * n_pool));
+      }
     }
-    return rc;
+    return rejoin(enqueue(0, n_steps));
   }
 
   // timing mode: everything on `stream`, HIP events around every kernel
