@@ -7,3 +7,4 @@ There is no CPU path and no PyTorch fallback: without a ROCm GPU or without the 
 from . import _lib  # noqa: F401
 from .table import FlatTable, padded_k  # noqa: F401
 from .engine import FMEngine, Hyper, normalize_inputs  # noqa: F401
+from .distributed import DataParallelFM, HipBackend  # noqa: F401

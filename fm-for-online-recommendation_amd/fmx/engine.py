@@ -110,11 +110,15 @@ class FMEngine:
         _lib.check(self.lib.fmx_sort_occurrences(self.table.c_struct(), idx_d.data_ptr(), B, self.workspace.data_ptr(),
                                                  self.error.data_ptr(), self._stream()))
 
-    def update(self, hyper, rule, B, xv_d, dz_first, dz_bi=None, gbi=None, inv_b=None, with_loss=True):
+    def update(self, hyper, rule, B, xv_d, dz_first, dz_bi=None, gbi=None, inv_b=None, with_loss=True, S=None, loss_b=None):
+        """Row-reduced backward + fused update for the batch whose occurrences self.sort() just listed.
+        S / loss_b default to the buffers the last forward() filled (a data-parallel caller passes gathered ones)."""
         inv_b = 1.0 / B if inv_b is None else inv_b
+        S = self.S if S is None else S
+        loss_b = self.loss_b if loss_b is None else loss_b
         _lib.check(self.lib.fmx_fm_update(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], self.workspace.data_ptr(),
-                                          _ptr(xv_d), self.S.data_ptr(), dz_first.data_ptr(), _ptr(dz_bi), _ptr(gbi), B,
-                                          self.loss_b.data_ptr() if with_loss else None, inv_b,
+                                          _ptr(xv_d), S.data_ptr(), dz_first.data_ptr(), _ptr(dz_bi), _ptr(gbi), B,
+                                          loss_b.data_ptr() if with_loss else None, inv_b,
                                           self.loss_out.data_ptr() if with_loss else None, self._stream()))
 
     def step(self, hyper, rule, loss, idx_d, xv_d, y_d, inv_b=None):

@@ -1,0 +1,116 @@
+"""The N > 1 host logic on CPU: world_size-2 gloo run of fmx.DataParallelFM with an oracle-backed compute backend
+(test infrastructure) must equal the single-process step on the same global batch, and both ranks must end with
+bit-identical replicas."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import fm_oracle as orc
+
+SIZES = [3, 9, 200, 1000, 17]
+K, B_LOCAL, STEPS = 8, 48, 3
+HYP = dict(alpha=0.05, beta=1.0, l1=0.001, l2=0.01)
+
+
+class OracleBackend:
+    """Test stand-in for fmx.HipBackend: the numpy oracle behind the same two calls (FTRL rule, BCEwl(z))."""
+
+    def __init__(self, state, offs):
+        self.st, self.offs = state, offs
+
+    def forward(self, idx, y, inv_b):
+        st = self.st
+        V = orc.ftrl_weight(st["zV"], st["nV"], **HYP)
+        w = orc.ftrl_weight(st["zw"], st["nw"], **HYP)
+        b = orc.ftrl_weight(st["zb"], st["nb"], **HYP)
+        rows = idx.numpy().astype(np.int64) + self.offs[None, :]
+        fw = orc.flat_forward(V, w, b, rows, np.ones(rows.shape, dtype=np.float32))
+        yv = y.numpy()
+        dz = orc.dloss_dlogit(fw["logit"], yv, "logits", inv_b)
+        return torch.from_numpy(fw["S"]), torch.from_numpy(dz), torch.from_numpy(orc.loss_value(fw["logit"], yv, "logits"))
+
+    def update(self, idx_g, S_g, dz_g, loss_g, inv_b):
+        st = self.st
+        V = orc.ftrl_weight(st["zV"], st["nV"], **HYP)
+        rows = idx_g.numpy().astype(np.int64) + self.offs[None, :]
+        S, dz = S_g.numpy(), dz_g.numpy()
+        x = np.ones(rows.shape, dtype=np.float32)
+        u, dV, dw = orc.flat_row_gradients(V, rows, x, S, dz, np.repeat(dz[:, None], V.shape[1], axis=1))
+        st["zV"][u], st["nV"][u] = orc.ftrl_step(st["zV"][u], st["nV"][u], dV, **HYP)
+        st["zw"][u], st["nw"][u] = orc.ftrl_step(st["zw"][u], st["nw"][u], dw, **HYP)
+        st["zb"], st["nb"] = orc.ftrl_step(st["zb"], st["nb"], dz.sum(dtype=np.float32), **HYP)
+        return torch.tensor([float(loss_g.numpy().sum(dtype=np.float32) * np.float32(inv_b))])
+
+
+def make_state():
+    rng = np.random.default_rng(3)
+    offs = np.concatenate([[0], np.cumsum(SIZES)]).astype(np.int64)
+    R = int(offs[-1])
+    V = (rng.normal(size=(R, K)) * 0.3).astype(np.float32)
+    w = (rng.normal(size=R) * 0.3).astype(np.float32)
+    st = dict(zV=orc.ftrl_z_for_weight(V, **HYP), nV=np.zeros_like(V), zw=orc.ftrl_z_for_weight(w, **HYP),
+              nw=np.zeros_like(w), zb=np.float32(0.0), nb=np.float32(0.0))
+    return st, offs[:-1]
+
+
+def make_batches(world):
+    rng = np.random.default_rng(9)
+    GB = B_LOCAL * world
+    out = []
+    for _ in range(STEPS):
+        idx = np.stack([rng.integers(0, s, size=GB) for s in SIZES], axis=1).astype(np.int32)
+        y = (rng.uniform(size=GB) < 0.3).astype(np.float32)
+        out.append((idx, y))
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fmx
+    st, offs = make_state()
+    dp = fmx.DataParallelFM(OracleBackend(st, offs))
+    losses = []
+    for idx, y in make_batches(world):
+        sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL)
+        losses.append(float(dp.step(torch.from_numpy(idx[sl]), torch.from_numpy(y[sl]))[0]))
+    q.put((rank, losses, {k: np.asarray(v).copy() for k, v in st.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process on the same global batches
+    import fmx
+    st, offs = make_state()
+    dp1 = fmx.DataParallelFM(OracleBackend(st, offs))
+    ref_losses = [float(dp1.step(torch.from_numpy(idx), torch.from_numpy(y))[0]) for idx, y in make_batches(world)]
+    for rank, losses, state in res:
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-6)
+        for k in st:
+            np.testing.assert_array_equal(state[k], np.asarray(st[k]), err_msg=f"rank {rank} {k}")   # bit-identical
+    for k in st:
+        np.testing.assert_array_equal(res[0][2][k], res[1][2][k])

@@ -404,3 +404,22 @@ def test_abi_rejects_bad_arguments(fmx):
     with pytest.raises(fmx._lib.FmxError) as ei:
         e2.sort(idx)
     assert ei.value.code == fmx._lib.ERR_UNSUPPORTED
+
+
+def test_data_parallel_wrapper_single_rank_equals_step(fmx):
+    """fmx.DataParallelFM with the HIP backend at world size 1 is the plain step (the N > 1 sharding / gather logic is
+    covered on CPU with gloo in tests/test_distributed_cpu.py)."""
+    sizes, k, B = MIXED_SIZES, 16, 700
+    pr = make_problem(sizes, k, B, seed=61)
+    hyp = fmx.Hyper(**HYP)
+    t1, t2 = weights_table(fmx, sizes, k, pr), weights_table(fmx, sizes, k, pr)
+    e1, e2 = fmx.FMEngine(t1, max_batch=B), fmx.FMEngine(t2, max_batch=B)
+    idx_d, _, y_d = e1.to_device(pr["idx"], None, pr["y"])
+    dp = fmx.DataParallelFM(fmx.HipBackend(e2, hyp, "signadam", "logits"))
+    for _ in range(3):
+        e1.step(hyp, "signadam", "logits", idx_d, None, y_d)
+        l1 = float(e1.loss_out.item())
+        l2 = float(dp.step(idx_d, y_d)[0])
+        assert l1 == l2
+    np.testing.assert_array_equal(t1.rows.cpu().numpy(), t2.rows.cpu().numpy())
+    np.testing.assert_array_equal(t1.bias.cpu().numpy(), t2.bias.cpu().numpy())

@@ -150,3 +150,43 @@ def test_flat_step_matches_class_step():
     assert_close(state["V"], V1, 1e-5, 1e-7, "V")
     assert_close(state["w"], w1, 1e-5, 1e-7, "w")
     assert_close(state["bias"], sd1["bias"], 1e-5, 1e-7, "bias")
+
+
+@pytest.mark.parametrize("rule,loss", [("signadam", "logits"), ("sgd", "sigmoid"), ("ftrl", "logits")])
+def test_c_oracle_matches_numpy_oracle(rule, loss):
+    """oracle/fm_oracle.c (the timed cpu_baseline port) against the golden-pinned numpy oracle."""
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/_build/liboracle.so not built (make -C oracle)")
+    rng = np.random.default_rng(12)
+    sizes = [3, 9, 1000, 5000, 4, 17, 200]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    R, k, B = int(offs[-1]), 8, 300
+    rows = np.stack([rng.integers(0, s, size=B) for s in sizes], axis=1) + offs[:-1][None, :]
+    x = rng.uniform(-1, 1, size=rows.shape).astype(np.float32)
+    y = (rng.uniform(size=B) < 0.3).astype(np.float32)
+    V = (rng.normal(size=(R, k)) * 0.3).astype(np.float32)
+    w = (rng.normal(size=R) * 0.3).astype(np.float32)
+    hyp = dict(lr=0.01, eps=1e-8, alpha=0.05, beta=1.0, l1=0.001, l2=0.01)
+    fh = {kk: hyp[kk] for kk in ("alpha", "beta", "l1", "l2")}
+    if rule == "ftrl":
+        mk = lambda: dict(zV=orc.ftrl_z_for_weight(V, **fh), nV=np.full_like(V, 0.2), zw=orc.ftrl_z_for_weight(w, **fh),
+                          nw=np.full_like(w, 0.2), zb=np.float32(0.1), nb=np.float32(0.3))
+        a, b = mk(), mk()
+        la = orc.flat_fm_step(a, rows, x, y, loss, rule, fh)["loss"]
+        lb = c_oracle.fm_step(b, rows, x, y, loss, rule, hyp)
+        keys = ("zV", "nV", "zw", "nw", "zb", "nb")
+    else:
+        mk = lambda: dict(V=V.copy(), w=w.copy(), bias=np.float32(0.37))
+        a, b = mk(), mk()
+        la = orc.flat_fm_step(a, rows, x, y, loss, rule, dict(lr=hyp["lr"]))["loss"]
+        lb = c_oracle.fm_step(b, rows, x, y, loss, rule, hyp)
+        keys = ("V", "w", "bias")
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
+    for kk in keys:
+        ref, got = np.asarray(a[kk], dtype=np.float64), np.asarray(b[kk], dtype=np.float64)
+        if rule == "signadam" and kk in ("V", "w"):
+            # sign-like rule: identical except where the summed gradient is within fp32 noise of zero
+            assert (np.abs(ref - got) > 1e-6).mean() < 2e-3
+        else:
+            np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6 * max(np.abs(ref).max(), 1e-3))
