@@ -49,8 +49,10 @@ def synth_pool(n_pool, B, sizes, seed, zipf=False):
 
 
 def cpu_baseline(idx_pool, y_pool, sizes, seconds=15.0):
-    """The oracle's flat FTRL step (numpy port of the same algorithm), timed on this host on a bounded sample."""
+    """The oracle's flat FTRL step, timed on this host on a bounded sample of the same stream: the C port
+    (oracle/fm_oracle.c, one thread) when oracle/_build/liboracle.so is present, else the numpy port."""
     from oracle import fm_oracle as orc
+    from oracle import c_oracle
     rng = np.random.default_rng(1)
     R = int(sum(sizes))
     h = {k: HYPER[k] for k in ("alpha", "beta", "l1", "l2")}
@@ -58,17 +60,23 @@ def cpu_baseline(idx_pool, y_pool, sizes, seconds=15.0):
     st = dict(zV=orc.ftrl_z_for_weight(V0, **h), nV=np.zeros((R, K_EMB), np.float32), zw=np.zeros(R, np.float32),
               nw=np.zeros(R, np.float32), zb=np.float32(0), nb=np.float32(0))
     offs = np.concatenate([[0], np.cumsum(sizes)])[:-1].astype(np.int64)
-    x = np.ones(idx_pool.shape[1:], dtype=np.float32)
+    use_c = c_oracle.available()
+    x = None if use_c else np.ones(idx_pool.shape[1:], dtype=np.float32)
     n, t0 = 0, time.perf_counter()
     while True:
         j = n % idx_pool.shape[0]
-        orc.flat_fm_step(st, idx_pool[j].astype(np.int64) + offs[None, :], x, y_pool[j], "logits", "ftrl", h)
+        rows = idx_pool[j].astype(np.int64) + offs[None, :]
+        if use_c:
+            c_oracle.fm_step(st, rows, None, y_pool[j], "logits", "ftrl", HYPER)
+        else:
+            orc.flat_fm_step(st, rows, x, y_pool[j], "logits", "ftrl", h)
         n += 1
-        if time.perf_counter() - t0 > seconds or n >= 64:
+        if time.perf_counter() - t0 > seconds or n >= 256:
             break
     dt = time.perf_counter() - t0
+    impl = "oracle/fm_oracle.c (plain C, gcc -O2, 1 thread)" if use_c else "oracle/fm_oracle.py flat_fm_step (numpy, 1 thread)"
     return dict(value=n * idx_pool.shape[1] / dt, unit="samples/s", cores=1, kind="port",
-                sample=f"{n} steps of B={idx_pool.shape[1]} of the same stream, oracle/fm_oracle.py flat_fm_step (numpy, 1 thread)")
+                sample=f"{n} steps of B={idx_pool.shape[1]} of the same synthetic stream through {impl}")
 
 
 def main():
@@ -93,10 +101,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # FMX_BENCH_REHEARSAL=1: every rank uses GPU 0 and gloo (to rehearse the N > 1 code path on a one-GPU box; the
+    # numbers of such a run mean nothing)
+    rehearsal = os.environ.get("FMX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- resident state: FTRL table (z, n) with V ~ N(0, 0.01) folded into z, first-order weights 0 ----
     RULE = args.rule
@@ -110,39 +126,61 @@ def main():
         table.rows[:, zo:zo + K_EMB] = fmx.table.ftrl_z_for_weight_torch(w0, table.ftrl)
     del w0
     hyper = fmx.Hyper(**HYPER)
-    eng = fmx.FMEngine(table, max_batch=BATCH)
+    eng = fmx.FMEngine(table, max_batch=BATCH * world)
     idx_np, y_np = synth_pool(N_POOL, BATCH, CRITEO_SIZES, SEED + 1000 * rank, zipf=args.zipf)
     idx_pool = torch.from_numpy(idx_np).to(dev)
     y_pool = torch.from_numpy(y_np).to(dev)
     loss_buf = torch.zeros(max(args.steps, args.warmup, 1), device=dev)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
-    # ---- warm-up, then EXACTLY K timed steps ----
-    eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.warmup, loss_buf)
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.steps, loss_buf, timed=True)
-    barrier()
-    dt = time.perf_counter() - t0
-    eng.check_error_flag()
-    losses = loss_buf[:args.steps].cpu().numpy()
-    assert np.isfinite(losses).all(), "non-finite loss in the timed region"
+    kernel_ms = None
+    if world == 1:
+        # ---- one GPU: the online loop of fmx_fm_stream over the resident pool.  Warm-up, then EXACTLY K timed steps ----
+        eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.warmup, loss_buf)
+        barrier()
+        t0 = time.perf_counter()
+        eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.steps, loss_buf)
+        barrier()
+        dt = time.perf_counter() - t0
+        eng.check_error_flag()
+        losses = loss_buf[:args.steps].cpu().numpy()
+        assert np.isfinite(losses).all(), "non-finite loss in the timed region"
+        # the same K steps once more with a HIP event pair around every launch (on the launch stream): per-kernel
+        # durations for the roofline.  The event traffic slows the loop down, so this pass is not the one timed above.
+        barrier()
+        t1 = time.perf_counter()
+        kernel_ms = eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.steps, loss_buf, timed=True)
+        barrier()
+        dt_events = time.perf_counter() - t1
+    else:
+        # ---- N GPUs: exact data parallelism (fmx.DataParallelFM): forward on the local slice, all-gather of the
+        #      low-rank factors (idx, S, dlogit) over RCCL, identical row-reduced update of the replicas ----
+        dp = fmx.DataParallelFM(fmx.HipBackend(eng, hyper, RULE, "logits"))
 
-    # the same K steps without per-launch events (informational: what the event bracketing costs)
-    barrier()
-    t1 = time.perf_counter()
-    eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.steps, loss_buf, timed=False)
-    barrier()
-    dt_noev = time.perf_counter() - t1
-
-    if world > 1:
-        tt = torch.tensor([dt, dt_noev], device=dev, dtype=torch.float64)
+        def run(n, first=0):
+            out = None
+            for s in range(n):
+                j = (first + s) % N_POOL
+                out = dp.step(idx_pool[j], y_pool[j])
+            return out
+        run(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        last = run(args.steps, args.warmup)
+        barrier()
+        dt = time.perf_counter() - t0
+        eng.check_error_flag()
+        losses = last.cpu().numpy()
+        assert np.isfinite(losses).all(), "non-finite loss in the timed region"
+        dt_events = float("nan")
+        tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, dt_noev = float(tt[0]), float(tt[1])
+        dt = float(tt[0])
 
     if rank != 0:
         if world > 1:
@@ -166,10 +204,8 @@ def main():
     stream_gbps = 5 * probe.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del probe
 
-    sort_ms, fwd_ms, upd_ms, fix_ms = [v / args.steps for v in kernel_ms]
     samples = args.steps * BATCH * world
     value = samples / dt
-    ach = BYTES_K_UPDATE * BATCH / (upd_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
@@ -185,27 +221,37 @@ def main():
         "config": {"workload": "online FM fwd+bwd + fused FTRL-proximal row update, synthetic Criteo-39 "
                                f"(R=1,006,628 rows, k=16, B={BATCH} per GPU, {'Zipf(1.05)' if args.zipf else 'uniform'} indices, "
                                "labels Bernoulli(0.3)); BASELINE.json configs[1]+[2]",
-                   "global_batch": BATCH * world, "row_stride_bytes": table.row_stride * 4,
-                   "hyper": HYPER, "pool_batches": N_POOL},
-        "roofline": {"bound": "hbm", "kernel": "k_fm_update", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": BYTES_K_UPDATE * BATCH, "avg_launch_ms": upd_ms},
-        "kernels_ms_per_step": {"k_sort_occ": sort_ms, "k_fm_forward": fwd_ms, "k_fm_update": upd_ms,
-                                "k_fm_fixup": fix_ms},
+                   "global_batch": BATCH * world, "row_stride_bytes": table.row_stride * 4, "rule": RULE,
+                   "hyper": HYPER, "pool_batches": N_POOL,
+                   "parallelism": "1 GPU" if world == 1 else f"dp{world}: replicated table, all-gather of (idx, S, dlogit), "
+                                                             "identical update on every replica (exact)"},
         "step_algorithmic": {"bytes_per_sample": BYTES_STEP_FTRL, "GBps": value / world * BYTES_STEP_FTRL / 1e9,
                              "frac_of_peak": value / world * BYTES_STEP_FTRL / 1e9 / HBM_PEAK_GBPS,
                              "frac_of_measured_stream_read": value / world * BYTES_STEP_FTRL / 1e9 / stream_gbps},
         "measured_stream_read_GBps": stream_gbps,
-        "ms_per_step_without_events": dt_noev / args.steps * 1e3,
-        "samples_per_s_without_events": samples / dt_noev,
         "final_loss": float(losses[-1]),
     }
-    if not args.no_cpu_baseline:
+    if kernel_ms is not None:
+        sort_ms, fwd_ms, upd_ms, fix_ms = [v / args.steps for v in kernel_ms]
+        ach = BYTES_K_UPDATE * BATCH / (upd_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_fm_update", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                           "algorithmic_bytes_per_launch": BYTES_K_UPDATE * BATCH, "avg_launch_ms": upd_ms,
+                           "measured": "HIP events on the launch stream around every k_fm_update launch, in a second "
+                                       "pass of the same K steps (profiles/ holds the rocprofv3 --kernel-trace --stats "
+                                       "summary of the same command)"}
+        out["kernels_ms_per_step"] = {"k_sort_occ": sort_ms, "k_fm_forward": fwd_ms, "k_fm_update": upd_ms,
+                                      "k_fm_fixup": fix_ms}
+        out["ms_per_step_event_pass"] = dt_events / args.steps * 1e3
+    else:
+        out["roofline"] = {"bound": "hbm", "kernel": "k_fm_update", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": None, "traffic": traffic, "measured": "per-kernel events are taken at N=1 only"}
+    if world > 1:
+        dist.destroy_process_group()
+    if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(idx_np, y_np, CRITEO_SIZES)
         out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
     print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -54,7 +54,13 @@ class DataParallelFM:
         out = self._bufs.get(key)
         if out is None:
             out = self._bufs[key] = torch.empty(shape, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        if local.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks sharing one GPU, where RCCL cannot run): stage through the host
+            host = torch.empty(shape, dtype=local.dtype)
+            dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         return out
 
     def step(self, idx_local, y_local):
