@@ -122,6 +122,11 @@ __device__ __forceinline__ float bcewl(float z, float y) {
 // k_sort_occ
 // ------------------------------------------------------------------------------------------------------------
 struct SortArgs {
+  int32_t debug;  // timing experiments only (FMX_SORT_DEBUG): 1 = skip the in-wave sort, 2 = skip the merge rounds, 3 = both
+  // one launch may sort several batches of a pool: workgroup (f, j) sorts field f of batch (pool_first + j) % n_pool into
+  // sorted + j * sorted_stride (n_batches == 1 and pool_stride == 0 for a single batch)
+  int32_t n_pool, pool_first, n_batches;
+  int64_t pool_stride, sorted_stride;  // in elements
   const int32_t *idx;
   const int64_t *foff;
   uint32_t *sorted;
@@ -194,11 +199,15 @@ __device__ __forceinline__ void bitonic_local(uint32_t (&v)[E], int tid, int k, 
   }
 }
 
-template <int E>
-__global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
-  extern __shared__ uint32_t sm[];
-  const int f = blockIdx.x;
-  const int tid = threadIdx.x, nt = blockDim.x;  // nt * E == Bp
+// Device body of the occurrence sort of ONE field (the calling workgroup: nt threads, nt * E == Bp).
+//   MERGE = true   every wave bitonic-sorts its 64 E composites in registers (no LDS, no barrier), then log2(nt / 64)
+//                  rounds of pairwise merging: every element finds its rank in the partner run by binary search in LDS
+//                  (composites are unique, so the merge is exact and stable).  Needs 2 * Bp words of LDS.
+//   MERGE = false  the full bitonic network with its cross-wave stages through LDS (Bp words): 78 dependent stages at
+//                  Bp = 4096 against 36 + 4 rounds above; kept for Bp > 16384 where two LDS buffers do not fit.
+template <int E, bool MERGE>
+__device__ __forceinline__ void sort_field(const SortArgs &a, int f, uint32_t *sm) {
+  const int tid = threadIdx.x, nt = blockDim.x;
   const uint32_t vocab = (uint32_t)(a.foff[f + 1] - a.foff[f]);
   uint32_t v[E];
 #pragma unroll
@@ -213,6 +222,70 @@ __global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
     v[r] = c;
   }
   const int wave_span = 64 * E;  // elements held by one wave
+  uint32_t *dst = a.sorted + (size_t)f * a.Bp;
+  if (MERGE) {
+    const int kmax = a.Bp < wave_span ? a.Bp : wave_span;
+    if (!(a.debug & 1))
+      for (int k = 2; k <= kmax; k <<= 1) bitonic_local<E>(v, tid, k, k >> 1);  // ascending runs of 64 E (i & k == 0 below 2 * span)
+    // NOTE: with the blocked layout wave w holds elements [w * span, (w + 1) * span): bit `span` of i alternates per wave,
+    // so odd waves come out DESCENDING from the bitonic levels above; the merge below reads them reversed.
+    if (a.Bp <= wave_span) {
+#pragma unroll
+      for (int r = 0; r < E; ++r) dst[tid * E + r] = v[r];
+      return;
+    }
+    uint32_t *cur = sm, *nxt = sm + a.Bp;
+    const int wave = tid >> 6;
+    {
+      // store the wave's run ascending: odd waves reverse their positions
+      const int base = wave * wave_span;
+      const bool desc = (wave & 1) != 0;
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const int pos = (tid & 63) * E + r;
+        cur[base + (desc ? wave_span - 1 - pos : pos)] = v[r];
+      }
+    }
+    __syncthreads();
+    for (int L = wave_span; L < a.Bp && !(a.debug & 2); L <<= 1) {  // merge runs of length L pairwise
+      uint32_t x[E];
+      const uint32_t *other[E];
+      int rank[E], dest0[E];
+      bool in_b[E];
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const int i = tid + r * nt;            // element handled by this thread in this round
+        const int pair = i / (2 * L);
+        const int off = i - pair * 2 * L;      // position inside the pair of runs
+        in_b[r] = off >= L;
+        x[r] = cur[i];
+        other[r] = cur + pair * 2 * L + (in_b[r] ? 0 : L);
+        dest0[r] = pair * 2 * L + (in_b[r] ? off - L : off);
+        rank[r] = 0;
+      }
+      // branch-free binary search, the E searches interleaved: rank = elements of the partner run that are < x for the
+      // left run, <= x for the right run (a stable merge; real composites are unique, the 0xFFFFFFFF padding is not)
+      for (int w = L >> 1; w >= 1; w >>= 1) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const uint32_t o = other[r][rank[r] + w - 1];
+          rank[r] += (in_b[r] ? o <= x[r] : o < x[r]) ? w : 0;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const uint32_t o = other[r][rank[r]];
+        rank[r] += (in_b[r] ? o <= x[r] : o < x[r]) ? 1 : 0;
+        nxt[dest0[r] + rank[r]] = x[r];
+      }
+      __syncthreads();
+      uint32_t *t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+    for (int i = tid; i < a.Bp; i += nt) dst[i] = cur[i];
+    return;
+  }
   const int half = a.Bp >> 1;
   for (int k = 2; k <= a.Bp; k <<= 1) {
     int j = k >> 1;
@@ -237,9 +310,19 @@ __global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
     }
     bitonic_local<E>(v, tid, k, j);
   }
-  uint32_t *dst = a.sorted + (size_t)f * a.Bp + (size_t)tid * E;
 #pragma unroll
-  for (int r = 0; r < E; ++r) dst[r] = v[r];
+  for (int r = 0; r < E; ++r) dst[(size_t)tid * E + r] = v[r];
+}
+
+template <int E, bool MERGE>
+__global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
+  extern __shared__ uint32_t sm[];
+  const int j = blockIdx.y;  // batch slot of this launch
+  if (j > 0 || a.pool_stride != 0) {
+    a.idx += (size_t)((a.pool_first + j) % a.n_pool) * a.pool_stride;
+    a.sorted += (size_t)j * a.sorted_stride;
+  }
+  sort_field<E, MERGE>(a, blockIdx.x, sm);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -828,10 +911,12 @@ int check_sort_geometry(const fmx_table_t *t, int B) {
 // ---- launch geometry knobs (waves per workgroup), overridable from the environment for experiments ----
 struct Tune {
   int wpb_fwd = 4, wpb_upd = 4;
-  int use_graph = 0;  // FMX_GRAPH=1 replays one pool pass as a hipGraph (measured slower on ROCm 7.2: the graph
-                      // executor serialises the sort branch; kept for re-measurement)
   int sort_e = 0;     // FMX_SORT_E: elements per thread of the bitonic sort (0 = default)
   int ext_events = 0; // FMX_EXT_EVENTS=1: completion events ride on the launches (hipExtLaunchKernel); slower on the host
+  int sort_debug = 0;
+  int sort_ahead = 4;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..4)
+  int sort_merge = 0; // FMX_SORT_MERGE=1: in-wave sort + binary-search merge rounds in LDS (measured slower: 31 vs 22 us,
+                      // the merge rounds are LDS-bandwidth bound)
   int sort_cus = 0;   // FMX_SORT_CUS=n: reserve n CUs for the side-stream sort (CU-masked library streams)
 };
 const Tune &tune() {
@@ -839,10 +924,12 @@ const Tune &tune() {
     Tune x;
     if (const char *e = getenv("FMX_WPB_FWD")) x.wpb_fwd = atoi(e);
     if (const char *e = getenv("FMX_WPB_UPD")) x.wpb_upd = atoi(e);
-    if (const char *e = getenv("FMX_GRAPH")) x.use_graph = atoi(e) ? 1 : 0;
     if (const char *e = getenv("FMX_SORT_E")) x.sort_e = atoi(e);
     if (const char *e = getenv("FMX_EXT_EVENTS")) x.ext_events = atoi(e);
     if (const char *e = getenv("FMX_SORT_CUS")) x.sort_cus = atoi(e);
+    if (const char *e = getenv("FMX_SORT_MERGE")) x.sort_merge = atoi(e);
+    if (const char *e = getenv("FMX_SORT_DEBUG")) x.sort_debug = atoi(e);
+    if (const char *e = getenv("FMX_SORT_AHEAD")) x.sort_ahead = atoi(e);
     auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
     if (!ok(x.wpb_fwd)) x.wpb_fwd = 4;
     if (!ok(x.wpb_upd)) x.wpb_upd = 4;
@@ -851,11 +938,13 @@ const Tune &tune() {
   return t;
 }
 
-// ---- workspace carving: [ sorted u32 F*Bp (x2: the online loop sorts batch t+1 while batch t is consumed) |
+constexpr int SORT_AHEAD_MAX = 4;  // batches sorted per side-stream launch in fmx_fm_stream
+
+// ---- workspace carving: [ sorted u32 F*Bp (x 2*SORT_AHEAD_MAX: the online loop sorts a group of batches ahead) |
 //                          meta i32 F*tiles*2 | parts f32 F*tiles*2*REC ], each 256-byte aligned ----
 struct Workspace {
-  uint32_t *sorted;   // buffer 0
-  uint32_t *sorted1;  // buffer 1
+  uint32_t *sorted;       // buffer 0 of a ring of 2 * SORT_AHEAD_MAX buffers, `sorted_stride` elements apart
+  size_t sorted_stride;
   int32_t *meta;
   int32_t *counter;  // step counter of fmx_fm_stream (one int32 in its own 256-byte slot)
   float *parts;
@@ -868,13 +957,13 @@ Workspace carve(const fmx_table_t *t, int B, void *base) {
   const size_t F = (size_t)t->n_fields, Bp = (size_t)fmx_sorted_width(B), tiles = Bp >> 6;
   const size_t rec = 2 * (size_t)t->kp + 4;
   const size_t o_sorted1 = align_up(F * Bp * 4, 256);
-  const size_t o_meta = 2 * o_sorted1;
+  const size_t o_meta = 2 * SORT_AHEAD_MAX * o_sorted1;
   const size_t o_counter = o_meta + align_up(F * tiles * 2 * 4, 256);
   const size_t o_parts = o_counter + 256;
   Workspace w;
   char *p = static_cast<char *>(base);
   w.sorted = reinterpret_cast<uint32_t *>(p);
-  w.sorted1 = reinterpret_cast<uint32_t *>(p + o_sorted1);
+  w.sorted_stride = o_sorted1 / 4;
   w.meta = reinterpret_cast<int32_t *>(p + o_meta);
   w.counter = reinterpret_cast<int32_t *>(p + o_counter);
   w.parts = reinterpret_cast<float *>(p + o_parts);
@@ -929,26 +1018,6 @@ Side *side_for_current_device() {
     if (!ok) return nullptr;
   }
   return &sd;
-}
-
-// ---- one cached hipGraph of the online loop per device, keyed by every argument baked into its kernel nodes ----
-struct GraphKey {
-  fmx_table_t table;
-  fmx_hyper_t hyper;
-  fmx_fwd_out_t fwd;
-  const void *idx_pool, *y_pool, *workspace, *loss_out, *stream;
-  int32_t rule, loss_kind, n_pool, B;
-  float inv_b;
-};
-struct GraphSlot {
-  GraphKey key;
-  hipGraphExec_t exec = nullptr;
-};
-GraphSlot *graph_slot_for_current_device() {
-  static GraphSlot slots[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  return &slots[dev];
 }
 
 constexpr int OVERLAP_MIN_BATCH = 512;  // below this the extra event traffic costs more than the sort
@@ -1018,13 +1087,21 @@ void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st
   launch_fixup<LPR>(a, rule, st, stop);
 }
 
+template <int E, bool MERGE>
+void launch_sort_m(const SortArgs &a, hipStream_t st, hipEvent_t stop) {
+  const int threads = a.Bp / E;
+  const uint32_t lds = (uint32_t)(a.Bp * sizeof(uint32_t)) * (MERGE ? 2u : 1u);
+  const dim3 grid(a.F, a.n_batches);
+  if (stop)  // the completion event rides on the launch packet: one runtime call instead of launch + hipEventRecord
+    hipExtLaunchKernelGGL((k_sort_occ<E, MERGE>), grid, dim3(threads), lds, st, nullptr, stop, 0, a);
+  else
+    hipLaunchKernelGGL((k_sort_occ<E, MERGE>), grid, dim3(threads), lds, st, a);
+}
+
 template <int E>
 void launch_sort(const SortArgs &a, hipStream_t st, hipEvent_t stop) {
-  const int threads = a.Bp / E;
-  if (stop)  // the completion event rides on the launch packet: one runtime call instead of launch + hipEventRecord
-    hipExtLaunchKernelGGL((k_sort_occ<E>), dim3(a.F), dim3(threads), (uint32_t)(a.Bp * sizeof(uint32_t)), st, nullptr, stop, 0, a);
-  else
-    hipLaunchKernelGGL((k_sort_occ<E>), dim3(a.F), dim3(threads), (size_t)a.Bp * sizeof(uint32_t), st, a);
+  if (a.Bp <= 8192 && tune().sort_merge) launch_sort_m<E, true>(a, st, stop);  // two LDS buffers within 64 KiB
+  else launch_sort_m<E, false>(a, st, stop);
 }
 
 int prepare_sort(int B) {
@@ -1033,18 +1110,29 @@ int prepare_sort(int B) {
   static bool raised = false;
   std::lock_guard<std::mutex> lock(mu);
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<8>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<16>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<32>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
     if (e != hipSuccess) return fail(FMX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     raised = true;
   }
   return FMX_OK;
 }
 
+struct SortBatch {  // several batches of a pool in one launch
+  int n_pool = 1, first = 0, n_batches = 1;
+  int64_t pool_stride = 0, sorted_stride = 0;
+};
+
 int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t *sorted, int32_t *error, hipStream_t st,
-              hipEvent_t stop = nullptr) {
+              hipEvent_t stop = nullptr, const SortBatch *mb = nullptr) {
   SortArgs a;
+  a.debug = tune().sort_debug;
+  a.n_pool = mb ? mb->n_pool : 1;
+  a.pool_first = mb ? mb->first : 0;
+  a.n_batches = mb ? mb->n_batches : 1;
+  a.pool_stride = mb ? mb->pool_stride : 0;
+  a.sorted_stride = mb ? mb->sorted_stride : 0;
   a.idx = idx;
   a.foff = table->field_offsets;
   a.sorted = sorted;
@@ -1256,15 +1344,16 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
   hipStream_t st = static_cast<hipStream_t>(stream);
   const Workspace w = carve(table, B, workspace);
   const size_t F = (size_t)table->n_fields;
-  uint32_t *const sorted[2] = {w.sorted, w.sorted1};
   int rc = FMX_OK;
 
   if (!kernel_ms) {
-    // production path.  Batch s+1 is sorted on the side stream while batch s runs forward / update on `stream`.
-    // Optionally (FMX_GRAPH=1) one pass over the pool (n_pool steps) is captured into a hipGraph and replayed.
+    // production path.  The occurrence sort does not depend on the weights: groups of `ahead` batches are sorted by ONE
+    // launch on the side stream while the previous group runs forward / update / fixup on `stream`.  Ring of
+    // 2 * ahead sorted buffers; per group one sort launch and four event operations, so the host issues ~4.25 runtime
+    // calls per step instead of 8 (at ~4 us each the per-batch version was host-bound).
     Side *sd = (B >= OVERLAP_MIN_BATCH && n_steps > 0) ? side_for_current_device() : nullptr;
     hipStream_t user = st;
-    const bool detour = sd && st == nullptr;  // the legacy default stream cannot be captured: detour through sd->main
+    const bool detour = sd && st == nullptr;  // the legacy default stream cannot be captured / is slow to enqueue on
     if (detour) {
       (void)hipEventRecord(sd->user_fork, user);
       st = sd->main;
@@ -1278,87 +1367,52 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
       return r;
     };
     (void)hipMemsetAsync(w.counter, 0, sizeof(int32_t), st);
-    const bool ext = tune().ext_events != 0;
-    auto enqueue = [&](int first, int count) -> int {
-      int r = FMX_OK;
-      if (count <= 0) return r;
+    int ahead = tune().sort_ahead;
+    if (ahead < 1) ahead = 1;
+    if (ahead > SORT_AHEAD_MAX) ahead = SORT_AHEAD_MAX;
+    auto sort_group = [&](int g, int first_step, hipStream_t where) -> int {  // steps [first_step, first_step + n)
+      const int n = (n_steps - first_step) < ahead ? (n_steps - first_step) : ahead;
+      SortBatch mb;
+      mb.n_pool = n_pool;
+      mb.first = first_step % n_pool;
+      mb.n_batches = n;
+      mb.pool_stride = (int64_t)B * (int64_t)F;
+      mb.sorted_stride = (int64_t)w.sorted_stride;
+      return sort_impl(table, idx_pool, B, w.sorted + (size_t)(g & 1) * ahead * w.sorted_stride, fwd->error, where, nullptr, &mb);
+    };
+    const int n_groups = (n_steps + ahead - 1) / ahead;
+    if (sd && n_groups > 0) {
+      (void)hipEventRecord(sd->fork, st);
+      (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
+      rc = sort_group(0, 0, sd->stream);
+      (void)hipEventRecord(sd->sorted[0], sd->stream);
+    }
+    for (int g = 0; g < n_groups && rc == FMX_OK; ++g) {
+      const int first_step = g * ahead;
+      const int n = (n_steps - first_step) < ahead ? (n_steps - first_step) : ahead;
       if (sd) {
-        (void)hipEventRecord(sd->fork, st);
-        (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
-        r = sort_impl(table, idx_pool + (size_t)(first % n_pool) * B * F, B, sorted[0], fwd->error, sd->stream);
-        (void)hipEventRecord(sd->sorted[0], sd->stream);
+        if (g + 1 < n_groups) {  // sort the next group while this one runs
+          if (g >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[(g + 1) & 1], 0);  // group g-1 is done with that half
+          rc = sort_group(g + 1, first_step + ahead, sd->stream);
+          (void)hipEventRecord(sd->sorted[(g + 1) & 1], sd->stream);
+        }
+      } else {
+        rc = sort_group(g, first_step, st);
       }
-      for (int s = 0; s < count && r == FMX_OK; ++s) {
-        const int j = (first + s) % n_pool, cur = s & 1, nxt = cur ^ 1;
+      for (int i = 0; i < n && rc == FMX_OK; ++i) {
+        const int s = first_step + i, j = s % n_pool;
         const int32_t *idx = idx_pool + (size_t)j * B * F;
         const float *y = y_pool + (size_t)j * B;
-        if (sd) {
-          if (s + 1 < count) {
-            if (s >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[nxt], 0);  // update(s-1) is done with buffer nxt
-            r = sort_impl(table, idx_pool + (size_t)((first + s + 1) % n_pool) * B * F, B, sorted[nxt], fwd->error, sd->stream,
-                          ext ? sd->sorted[nxt] : nullptr);
-            if (!ext) (void)hipEventRecord(sd->sorted[nxt], sd->stream);
-          }
-        } else {
-          r = sort_impl(table, idx, B, sorted[cur], fwd->error, st);
-        }
-        if (r == FMX_OK) r = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
-        if (sd) (void)hipStreamWaitEvent(st, sd->sorted[cur], 0);
-        if (r == FMX_OK)
-          r = update_impl(table, hyper, rule, w, sorted[cur], nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                          loss_out, st, nullptr, loss_out ? w.counter : nullptr, (sd && ext) ? sd->consumed[cur] : nullptr);
-        if (sd && !ext) (void)hipEventRecord(sd->consumed[cur], st);
+        const uint32_t *sorted = w.sorted + ((size_t)(g & 1) * ahead + i) * w.sorted_stride;
+        rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
+        if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
+        if (rc == FMX_OK)
+          rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
+                           loss_out, st, nullptr, loss_out ? w.counter : nullptr);
       }
-      return r;
-    };
-    const int n_graph = (sd && tune().use_graph) ? n_steps / n_pool : 0;
-    if (n_graph > 0) {
-      GraphKey key{};
-      key.table = *table;
-      key.hyper = *hyper;
-      key.fwd = *fwd;
-      key.idx_pool = idx_pool;
-      key.y_pool = y_pool;
-      key.workspace = workspace;
-      key.loss_out = loss_out;
-      key.stream = st;  // (sd->main when detouring)
-      key.rule = rule;
-      key.loss_kind = loss_kind;
-      key.n_pool = n_pool;
-      key.B = B;
-      key.inv_b = inv_b;
-      GraphSlot *slot = graph_slot_for_current_device();
-      if (slot && !(slot->exec && memcmp(&slot->key, &key, sizeof(key)) == 0)) {
-        if (slot->exec) {
-          (void)hipGraphExecDestroy(slot->exec);
-          slot->exec = nullptr;
-        }
-        if (int r = prepare_sort(B)) return rejoin(r);  // k_sort_occ raises its LDS limit on first use: not inside a capture
-        hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-          rc = enqueue(0, n_pool);
-          e = hipStreamEndCapture(st, &graph);
-        }
-        if (e == hipSuccess && rc == FMX_OK) e = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
-        if (graph) (void)hipGraphDestroy(graph);
-        if (e != hipSuccess || rc != FMX_OK) {
-          slot->exec = nullptr;
-          (void)hipGetLastError();
-          if (rc != FMX_OK) return rejoin(rc);
-          return rejoin(fail(FMX_ERR_LAUNCH, "hipGraph capture of the online loop failed: %s", hipGetErrorString(e)));
-        }
-        slot->key = key;
-      }
-      if (slot && slot->exec) {
-        for (int g = 0; g < n_graph; ++g) {
-          hipError_t e = hipGraphLaunch(slot->exec, st);
-          if (e != hipSuccess) return rejoin(fail(FMX_ERR_LAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e)));
-        }
-        return rejoin(enqueue(n_graph * n_pool, n_steps - n_graph * n_pool));
-      }
+      if (sd) (void)hipEventRecord(sd->consumed[g & 1], st);
     }
-    return rejoin(enqueue(0, n_steps));
+    return rejoin(rc);
   }
 
   // timing mode: everything on `stream`, HIP events around every kernel
