@@ -1,0 +1,82 @@
+"""SFTRL_CCFM -- drop-in for reference models/models_online/SFTRL_CCFM.py:18-121 (sketched FTRL, convex-concave FM).
+
+y_hat = ||BP^T x||^2 - ||BN^T x||^2 (:42-44); the gradient sign s picks the sketch: s <= 0 appends sqrt(-eta s) x to
+BP, s > 0 appends sqrt(eta s) x to BN (:77-121).  Host fp64 like the reference's CPU path; see _sketch.py."""
+import time
+
+import numpy as np
+import torch
+
+from models.models_online.FM_Base import FM_Base
+from models.models_online._sketch import Sketch
+
+Tensor_type = torch.DoubleTensor
+
+
+class SFTRL_CCFM(FM_Base):
+    _linear_term = False
+
+    def __init__(self, inputs_matrix, outputs, task, learning_rate, num_feature):
+        super(SFTRL_CCFM, self).__init__(inputs_matrix, outputs, task, learning_rate, num_feature)
+        self.model_name = "SFTRL_CCFM"
+        self.row_count_p = 0
+        self.row_count_n = 0
+        d = self._sketch_dim()
+        self.BT_P = Tensor_type(np.zeros([d, 2 * self.m]))
+        self.BT_N = Tensor_type(np.zeros([d, 2 * self.m]))
+
+    def _sketch_dim(self):
+        return self.num_feature
+
+    def online_learning(self):
+        start = time.time()
+        print("==" * 20)
+        print(self.model_name + "_" + str(self.eta) + "_" + str(self.m) + "_start")
+        if self.task not in ("cls", "reg"):
+            raise NotImplementedError
+        cls = self.task == "cls"
+        X = self.At.t().contiguous().numpy().astype(np.float64, copy=False)
+        y = np.asarray(self.b.reshape(-1).numpy(), dtype=np.float64)
+        d = self._sketch_dim()
+        P, N = Sketch(d, self.m, self._thres), Sketch(d, self.m, self._thres)
+        P.B, P.count = self.BT_P.numpy().copy(), self.row_count_p
+        N.B, N.count = self.BT_N.numpy().copy(), self.row_count_n
+        w = g_w = None
+        if self._linear_term:
+            w, g_w = self.w.numpy().reshape(-1).copy(), self.g_w.numpy().reshape(-1).copy()
+        preds = np.empty((self.num_data,) + self._pred_shape(cls), dtype=np.float64)
+        for idx in range(self.num_data):
+            x = X[idx]
+            xs = x[:d]
+            scalar = P.energy(xs) - N.energy(xs)
+            if self._linear_term:
+                scalar += float(w @ x)
+            if np.isnan(scalar):
+                raise ValueError("Nan contained")
+            if cls:
+                pred = 1.0 if scalar >= 0 else -1.0
+                sign = (-1.0 / (1.0 + np.exp(scalar * y[idx]))) * y[idx]
+            else:
+                pred = scalar
+                sign = 2.0 * (scalar - y[idx])
+            if self._linear_term:
+                g_w += sign * x
+                w = -self.eta * g_w
+            if sign <= 0:
+                P.append(np.sqrt(-self.eta * sign) * xs)
+            else:
+                N.append(np.sqrt(self.eta * sign) * xs)
+            preds[idx] = pred
+            if idx % 1000 == 0:
+                print(" %d th : pred %f , real %f " % (idx, pred, y[idx]))
+        self.BT_P, self.row_count_p = torch.from_numpy(P.B.copy()), P.count
+        self.BT_N, self.row_count_n = torch.from_numpy(N.B.copy()), N.count
+        if self._linear_term:
+            self.w = torch.from_numpy(w.reshape(-1, 1).copy())
+            self.g_w = torch.from_numpy(g_w.reshape(-1, 1).copy())
+        end = time.time()
+        print("learning time : %f " % (end - start))
+        return preds, y.copy(), (end - start)
+
+    def _pred_shape(self, cls):
+        return (1,) if cls else ()

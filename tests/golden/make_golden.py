@@ -272,9 +272,50 @@ def data_manager_fixture():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def path_b_family_fixture():
+    """G9: SFTRL_CCFM, SFTRL_Vanila, RRF_Online (cls and reg) on a seeded 300x8 stream."""
+    from models.models_online.SFTRL_CCFM import SFTRL_CCFM
+    from models.models_online.SFTRL_Vanila import SFTRL_Vanila
+    from models.models_online.RRF_Online import RRF_Online
+    out = {}
+    rng = np.random.default_rng(91)
+    N, d, m = 300, 8, 4
+    X = rng.uniform(-1, 1, size=(N, d))
+    for task in ("cls", "reg"):
+        y = np.where(rng.uniform(size=N) < 0.5, -1.0, 1.0) if task == "cls" else rng.normal(size=N)
+        out[f"{task}/X"], out[f"{task}/y"] = X, y
+        for name, cls in (("SFTRL_CCFM", SFTRL_CCFM), ("SFTRL_Vanila", SFTRL_Vanila)):
+            model = cls(torch.DoubleTensor(X), torch.DoubleTensor(y), task, 0.05, m)
+            with redirect_stdout(io.StringIO()):
+                pred, real, _ = model.online_learning()
+            out[f"{task}/{name}/pred"] = np.asarray([np.asarray(p, dtype=np.float64) for p in pred])
+            out[f"{task}/{name}/pred_shape"] = np.asarray(np.asarray(pred).shape)
+            out[f"{task}/{name}/real"] = np.asarray([float(r) for r in real])
+            out[f"{task}/{name}/BTP_gram"] = (model.BT_P.matmul(model.BT_P.t())).numpy()
+            out[f"{task}/{name}/BTN_gram"] = (model.BT_N.matmul(model.BT_N.t())).numpy()
+            out[f"{task}/{name}/counts"] = np.asarray([model.row_count_p, model.row_count_n])
+            if name == "SFTRL_Vanila":
+                out[f"{task}/{name}/w"] = model.w.numpy()
+        # RRF's cls dynamics amplify rounding differences (1e-16 after 100 steps -> 1e-3 after 300): pin 100 steps
+        seed_all(17)
+        model = RRF_Online(torch.DoubleTensor(X[:100]), torch.DoubleTensor(y[:100]), task, num_sampled_spectral=6)
+        with redirect_stdout(io.StringIO()):
+            pred, real, _ = model.online_learning()
+        out[f"{task}/RRF/pred"] = np.asarray([np.asarray(p, dtype=np.float64) for p in pred])
+        out[f"{task}/RRF/pred_shape"] = np.asarray(np.asarray(pred).shape)
+        out[f"{task}/RRF/real"] = np.asarray([float(r) for r in real])
+        out[f"{task}/RRF/w"], out[f"{task}/RRF/gamma"] = model.w.numpy(), model.gamma.numpy()
+    path = os.path.join(HERE, "path_b_family.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
     if "--only-data-manager" in sys.argv:
         data_manager_fixture()
+        return
+    if "--only-path-b" in sys.argv:
+        path_b_family_fixture()
         return
     assert any(p.rstrip("/") == "/root/reference" for p in sys.path), "run with PYTHONPATH=/root/reference"
     rng = np.random.default_rng(39)
@@ -285,6 +326,7 @@ def main():
     fm_ftrl_fixture()
     preprocess_fixture()
     data_manager_fixture()
+    path_b_family_fixture()
 
 
 if __name__ == "__main__":

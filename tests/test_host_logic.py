@@ -189,3 +189,50 @@ def test_data_manager_and_metrics_vs_reference(golden_dir, tmp_path):
     m, acc = mm.classfication_metric(sp, sr)
     np.testing.assert_allclose(m, z["metric/cls"], rtol=1e-12)
     np.testing.assert_allclose(acc, z["metric/cls_acc"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("task", ["cls", "reg"])
+@pytest.mark.parametrize("name", ["SFTRL_CCFM", "SFTRL_Vanila"])
+def test_sketched_ftrl_vs_reference(name, task, golden_dir, capsys):
+    """The sketched FTRL family (host fp64): predictions, sketch Gram matrices (sign-invariant) and counters."""
+    import torch
+    from models.models_online.SFTRL_CCFM import SFTRL_CCFM
+    from models.models_online.SFTRL_Vanila import SFTRL_Vanila
+    z = np.load(os.path.join(golden_dir, "path_b_family.npz"))
+    cls = dict(SFTRL_CCFM=SFTRL_CCFM, SFTRL_Vanila=SFTRL_Vanila)[name]
+    m = cls(torch.DoubleTensor(z[f"{task}/X"]), torch.DoubleTensor(z[f"{task}/y"]), task, 0.05, 4)
+    pred, real, secs = m.online_learning()
+    out = capsys.readouterr().out
+    assert out.startswith("=" * 40 + f"\n{name}_0.05_4_start\n 0 th : pred ")
+    assert tuple(pred.shape) == tuple(z[f"{task}/{name}/pred_shape"])
+    np.testing.assert_allclose(pred, z[f"{task}/{name}/pred"].reshape(pred.shape), rtol=1e-7, atol=1e-9)
+    np.testing.assert_array_equal(real, z[f"{task}/{name}/real"])
+    assert [m.row_count_p, m.row_count_n] == list(z[f"{task}/{name}/counts"])
+    np.testing.assert_allclose((m.BT_P @ m.BT_P.t()).numpy(), z[f"{task}/{name}/BTP_gram"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose((m.BT_N @ m.BT_N.t()).numpy(), z[f"{task}/{name}/BTN_gram"], rtol=1e-7, atol=1e-10)
+    if name == "SFTRL_Vanila":
+        np.testing.assert_allclose(m.w.numpy(), z[f"{task}/{name}/w"], rtol=1e-9, atol=1e-12)
+    assert m.model_name == name and isinstance(secs, float)
+
+
+@pytest.mark.parametrize("task", ["cls", "reg"])
+def test_rrf_online_vs_reference(task, golden_dir, capsys):
+    import random
+    import torch
+    from models.models_online.RRF_Online import RRF_Online
+    z = np.load(os.path.join(golden_dir, "path_b_family.npz"))
+    torch.manual_seed(17)
+    np.random.seed(17)
+    random.seed(17)
+    m = RRF_Online(torch.DoubleTensor(z[f"{task}/X"][:100]), torch.DoubleTensor(z[f"{task}/y"][:100]), task,
+                   num_sampled_spectral=6)
+    assert m.loss_type == ("logit" if task == "cls" else "l2")
+    pred, real, _ = m.online_learning()
+    capsys.readouterr()
+    assert tuple(pred.shape) == tuple(z[f"{task}/RRF/pred_shape"])
+    np.testing.assert_allclose(pred, z[f"{task}/RRF/pred"].reshape(pred.shape), rtol=1e-8, atol=1e-10)
+    np.testing.assert_array_equal(real, z[f"{task}/RRF/real"])
+    np.testing.assert_allclose(m.w.numpy(), z[f"{task}/RRF/w"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(m.gamma.numpy(), z[f"{task}/RRF/gamma"], rtol=1e-8, atol=1e-11)
+    with pytest.raises(NotImplementedError):
+        RRF_Online(torch.DoubleTensor(z["cls/X"]), torch.DoubleTensor(z["cls/y"]), "cls", loss_type="x").online_learning()
