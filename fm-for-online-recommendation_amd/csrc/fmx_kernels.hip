@@ -914,7 +914,8 @@ struct Tune {
   int sort_e = 0;     // FMX_SORT_E: elements per thread of the bitonic sort (0 = default)
   int ext_events = 0; // FMX_EXT_EVENTS=1: completion events ride on the launches (hipExtLaunchKernel); slower on the host
   int sort_debug = 0;
-  int sort_ahead = 4;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..4)
+  int stream_prio = 1;  // FMX_STREAM_PRIO=0: no stream priorities
+  int sort_ahead = 8;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..8)
   int sort_merge = 0; // FMX_SORT_MERGE=1: in-wave sort + binary-search merge rounds in LDS (measured slower: 31 vs 22 us,
                       // the merge rounds are LDS-bandwidth bound)
   int sort_cus = 0;   // FMX_SORT_CUS=n: reserve n CUs for the side-stream sort (CU-masked library streams)
@@ -930,6 +931,7 @@ const Tune &tune() {
     if (const char *e = getenv("FMX_SORT_MERGE")) x.sort_merge = atoi(e);
     if (const char *e = getenv("FMX_SORT_DEBUG")) x.sort_debug = atoi(e);
     if (const char *e = getenv("FMX_SORT_AHEAD")) x.sort_ahead = atoi(e);
+    if (const char *e = getenv("FMX_STREAM_PRIO")) x.stream_prio = atoi(e);
     auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
     if (!ok(x.wpb_fwd)) x.wpb_fwd = 4;
     if (!ok(x.wpb_upd)) x.wpb_upd = 4;
@@ -938,7 +940,7 @@ const Tune &tune() {
   return t;
 }
 
-constexpr int SORT_AHEAD_MAX = 4;  // batches sorted per side-stream launch in fmx_fm_stream
+constexpr int SORT_AHEAD_MAX = 8;  // batches sorted per side-stream launch in fmx_fm_stream
 
 // ---- workspace carving: [ sorted u32 F*Bp (x 2*SORT_AHEAD_MAX: the online loop sorts a group of batches ahead) |
 //                          meta i32 F*tiles*2 | parts f32 F*tiles*2*REC ], each 256-byte aligned ----
@@ -1005,8 +1007,12 @@ Side *side_for_current_device() {
                hipExtStreamCreateWithCUMask(&sd.main, words, m_main) == hipSuccess;
     }
     if (!masked) {
-      if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-      if (hipStreamCreateWithFlags(&sd.main, hipStreamNonBlocking) != hipSuccess) return nullptr;
+      // the sort is background work: lowest stream priority for it, highest for the stand-in main stream
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      const bool prio = tune().stream_prio != 0;
+      if (hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, prio ? lo : 0) != hipSuccess) return nullptr;
+      if (hipStreamCreateWithPriority(&sd.main, hipStreamNonBlocking, prio ? hi : 0) != hipSuccess) return nullptr;
     }
     bool ok = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&sd.user_fork, hipEventDisableTiming) == hipSuccess &&
@@ -1349,7 +1355,7 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
   if (!kernel_ms) {
     // production path.  The occurrence sort does not depend on the weights: groups of `ahead` batches are sorted by ONE
     // launch on the side stream while the previous group runs forward / update / fixup on `stream`.  Ring of
-    // 2 * ahead sorted buffers; per group one sort launch and four event operations, so the host issues ~4.25 runtime
+    // 2 * ahead sorted buffers; per group one sort launch and four event operations, so the host issues ~3.6 runtime
     // calls per step instead of 8 (at ~4 us each the per-batch version was host-bound).
     Side *sd = (B >= OVERLAP_MIN_BATCH && n_steps > 0) ? side_for_current_device() : nullptr;
     hipStream_t user = st;

@@ -106,8 +106,8 @@ int fmx_sorted_width(int B);
 int fmx_sorted_bbits(int B);
 
 /* Bytes of caller-owned device workspace a step of batch size B needs (16-byte aligned).  Layout:
- *   sorted  uint32 [8][F, Bp]        occurrence lists: (local index << bbits) | sample, padded with 0xFFFFFFFF
- *                                    (a ring of 8: fmx_fm_stream sorts up to 4 batches ahead; single steps use the first)
+ *   sorted  uint32 [16][F, Bp]       occurrence lists: (local index << bbits) | sample, padded with 0xFFFFFFFF
+ *                                    (a ring of 16: fmx_fm_stream sorts up to 8 batches ahead; single steps use the first)
  *   meta    int32  [F, Bp/64, 2]     per 64-entry tile: does a run come in from / go out to the neighbouring tile
  *   parts   float  [F, Bp/64, 2, 2*kp+4]  partial sums of the runs that cross a tile boundary
  * Negative on a bad table. */
