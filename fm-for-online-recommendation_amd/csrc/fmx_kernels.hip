@@ -156,6 +156,15 @@ __device__ __forceinline__ uint32_t xor_lane(uint32_t v, int lane) {
   }
 }
 
+template <int M>
+__device__ __forceinline__ float xor_lane_f(float v, int lane) {
+  return __uint_as_float(xor_lane<M>(__float_as_uint(v), lane));
+}
+template <int M>
+__device__ __forceinline__ float4 xor_lane_f4(float4 v, int lane) {
+  return {xor_lane_f<M>(v.x, lane), xor_lane_f<M>(v.y, lane), xor_lane_f<M>(v.z, lane), xor_lane_f<M>(v.w, lane)};
+}
+
 // Bitonic network on N = Bp composites held E per thread in a blocked layout (element i = tid * E + r):
 //   partner distance j <  E        in-thread compare-exchange
 //   E <= j < 64 E                  partner in another lane of the wave: xor_lane<j / E>
@@ -411,13 +420,15 @@ __global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
   }
   if (bad && a.out.error) *a.out.error = 1;
 
-  // field sums: butterfly over the slots (lanes with equal q)
-#pragma unroll
-  for (int m = LPR; m < WAVE; m <<= 1) {
-    s = s + shfl_xor4(s, m);
-    ss = ss + shfl_xor4(ss, m);
-    fo += __shfl_xor(fo, m);
+  // field sums: butterfly over the slots (lanes with equal q), DPP / permlane exchanges (no LDS crossbar)
+#define FMX_BFLY(M)                               \
+  if (LPR <= M) {                                 \
+    s = s + xor_lane_f4<M>(s, lane);              \
+    ss = ss + xor_lane_f4<M>(ss, lane);           \
+    fo += xor_lane_f<M>(fo, lane);                \
   }
+  FMX_BFLY(1) FMX_BFLY(2) FMX_BFLY(4) FMX_BFLY(8) FMX_BFLY(16) FMX_BFLY(32)
+#undef FMX_BFLY
   const float4 bi = 0.5f * (s * s - ss);
   float sbi = (bi.x + bi.y) + (bi.z + bi.w);
 #pragma unroll
@@ -636,8 +647,19 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   const int e0 = base + slot * EPG;
 
   uint32_t c[EPG];
+  if constexpr (EPG % 4 == 0) {  // 16-byte loads (e0 is a multiple of EPG)
 #pragma unroll
-  for (int j = 0; j < EPG; ++j) c[j] = sf[e0 + j];
+    for (int j = 0; j < EPG; j += 4) {
+      const uint4 t = *reinterpret_cast<const uint4 *>(sf + e0 + j);
+      c[j] = t.x;
+      c[j + 1] = t.y;
+      c[j + 2] = t.z;
+      c[j + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < EPG; ++j) c[j] = sf[e0 + j];
+  }
   const uint32_t kprev = (e0 == 0 ? SENT : sf[e0 - 1]) >> bbits;
   const uint32_t knext = (e0 + EPG < a.Bp ? sf[e0 + EPG] : SENT) >> bbits;
   const uint32_t tile_prevkey = (base == 0 ? SENT : sf[base - 1]) >> bbits;
@@ -679,8 +701,9 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
       const uint32_t b = c[j] & bmask;
       const float4 S4 = *reinterpret_cast<const float4 *>(a.S + (size_t)b * kp + 4 * q);
       const float x = a.xv ? a.xv[(size_t)b * a.F + f] : 1.f;
-      const float dzb = a.dz_bi ? a.dz_bi[b] : 0.f;
-      cw[j] = x * a.dz_first[b];
+      const float dzf = a.dz_first[b];
+      const float dzb = a.dz_bi == a.dz_first ? dzf : (a.dz_bi ? a.dz_bi[b] : 0.f);
+      cw[j] = x * dzf;
       if constexpr (HAS_GBI) {
         const float4 G = splat(dzb) + *reinterpret_cast<const float4 *>(a.gbi + (size_t)b * kp + 4 * q);
         const float4 xG = x * G;

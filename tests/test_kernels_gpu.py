@@ -423,3 +423,43 @@ def test_data_parallel_wrapper_single_rank_equals_step(fmx):
         assert l1 == l2
     np.testing.assert_array_equal(t1.rows.cpu().numpy(), t2.rows.cpu().numpy())
     np.testing.assert_array_equal(t1.bias.cpu().numpy(), t2.bias.cpu().numpy())
+
+
+@pytest.mark.parametrize("F,k,B", [(1, 4, 65), (2, 8, 129), (70, 16, 257), (5, 24, 300), (3, 64, 200), (39, 7, 64), (17, 16, 8192)])
+def test_step_shape_sweep(fmx, F, k, B):
+    """Template paths the Criteo shape does not reach: 1 / 2 / 8 / 16 lanes per row, the generic field loop (F > 64),
+    batch sizes straddling the 64-entry tiles, and the largest single-buffer sort width."""
+    rng = np.random.default_rng(F * 1000 + k)
+    sizes = [int(s) for s in rng.choice([1, 2, 3, 5, 40, 700, 20000], size=F)]
+    for rule in ("sgd", "ftrl"):
+        pr = make_problem(sizes, k, B, seed=F + k + B, real_x=(F % 2 == 1))
+        hyp = fmx.Hyper(**HYP)
+        x = pr["x"] if pr["x"] is not None else np.ones((B, F), dtype=np.float32)
+        if rule == "sgd":
+            pr, t, state, outs = run_step_weights(fmx, sizes, k, B, "sgd", "logits", seed=F + k + B, real_x=(F % 2 == 1))
+            close(outs[0][1], outs[0][0]["loss"], 1e-5, 1e-7, "loss")
+            check_weights_after(pr, t, state, outs[0][0], "sgd", k)
+            continue
+        st = ftrl_state(pr, HYP)
+        st0 = {kk: np.array(v, copy=True) for kk, v in st.items()}
+        t = ftrl_table(fmx, sizes, k, st)
+        eng = fmx.FMEngine(t, max_batch=B)
+        idx_d, xv_d, y_d = eng.to_device(pr["idx"], pr["x"], pr["y"])
+        eng.step(hyp, "ftrl", "sigmoid", idx_d, xv_d, y_d)
+        torch.cuda.synchronize()
+        eng.check_error_flag()
+        h = dict(alpha=HYP["alpha"], beta=HYP["beta"], l1=HYP["l1"], l2=HYP["l2"])
+        out = orc.flat_fm_step(st, pr["rows"], x, pr["y"], "sigmoid", "ftrl", h)
+        close(float(eng.loss_out.item()), out["loss"], 1e-5, 1e-7, "loss")
+        zV, nV, zw, nw = [a.numpy() for a in t.export_ftrl_state()]
+        u = out["urows"]
+        touched = np.zeros(pr["R"], dtype=bool)
+        touched[u] = True
+        np.testing.assert_array_equal(zV[~touched], st0["zV"][~touched])
+        g2 = (out["dV"].astype(np.float64) ** 2).max()
+        close(nV[u] - st0["nV"][u], st["nV"][u] - st0["nV"][u], 5e-5, 2e-6 * g2 + 1.2e-7 * st0["nV"][u], "nV")
+        close(nw[u] - st0["nw"][u], st["nw"][u] - st0["nw"][u], 5e-5,
+              2e-6 * (out["dw"].astype(np.float64) ** 2).max() + 1.2e-7 * st0["nw"][u], "nw")
+        # the cached weights equal the weights derived from the stored (z, n)
+        Vc = t.rows[:, :k].cpu().numpy()
+        np.testing.assert_allclose(Vc, orc.ftrl_weight(zV, nV, **h), rtol=2e-6, atol=1e-7)
