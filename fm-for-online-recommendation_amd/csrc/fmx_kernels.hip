@@ -821,14 +821,24 @@ __global__ __launch_bounds__(256) void k_fm_fixup(UpdArgs a) {
   const int tiles_per_field = a.Bp >> 6;
   const int gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (gt >= a.F * tiles_per_field) return;
-  if (a.meta[(size_t)gt * 2 + 1] != 1) return;  // wave-uniform
   const int f = gt / tiles_per_field;
   const int t = gt - f * tiles_per_field;
+  // three dependent round trips instead of five: the head flag, the run's key (last entry of the tile) and the meta of
+  // the following tiles are loaded together; the row is requested as soon as the key is known, before the partial
+  // records are summed
+  const int my_trail = a.meta[(size_t)gt * 2 + 1];
+  const uint32_t key = a.sorted[(size_t)f * a.Bp + ((size_t)t << 6) + 63] >> a.bbits;
+  const int tj0 = t + 1 + lane;
+  const int st0 = tj0 < tiles_per_field ? a.meta[((size_t)f * tiles_per_field + tj0) * 2] : LEAD_NONE;
+  if (my_trail != 1) return;  // wave-uniform
+  float *rp = a.rows + ((size_t)a.foff[f] + key) * (size_t)a.stride;
+  RowRegs r;
+  if (lane < LPR) r = load_row<LAYOUT>(rp, q, kp, a.zoff);
   // m = number of following tiles that hold a piece of the run
   int m = 0;
   for (int j0 = 1; t + j0 < tiles_per_field; j0 += 64) {
     const int tj = t + j0 + lane;
-    const int st = tj < tiles_per_field ? a.meta[((size_t)f * tiles_per_field + tj) * 2] : LEAD_NONE;
+    const int st = j0 == 1 ? st0 : (tj < tiles_per_field ? a.meta[((size_t)f * tiles_per_field + tj) * 2] : LEAD_NONE);
     const unsigned long long stop = __ballot(st != LEAD_THROUGH);
     if (stop != 0ull) {
       const int pos = __ffsll((long long)stop) - 1;
@@ -853,12 +863,7 @@ __global__ __launch_bounds__(256) void k_fm_fixup(UpdArgs a) {
     aA = aA + shfl_xor4(aA, mm);
     aw += __shfl_xor(aw, mm);
   }
-  if (lane < LPR) {
-    const uint32_t key = a.sorted[(size_t)f * a.Bp + ((size_t)t << 6) + 63] >> a.bbits;
-    float *rp = a.rows + ((size_t)a.foff[f] + key) * (size_t)a.stride;
-    const RowRegs r = load_row<LAYOUT>(rp, q, kp, a.zoff);
-    update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, aV, aA, aw, a.h);
-  }
+  if (lane < LPR) update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, aV, aA, aw, a.h);
 }
 
 // ------------------------------------------------------------------------------------------------------------
