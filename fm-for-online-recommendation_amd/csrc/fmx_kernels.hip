@@ -867,6 +867,174 @@ __global__ __launch_bounds__(256) void k_fm_fixup(UpdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_mlp_small: the relu MLP on top of the bi-interaction vector for the online (small batch) steps of DeepFM / NFM
+// (reference deepfm_adam.py:82-88,106-119) and the ONN classes' Hedge backprop (deepfm_onn.py:88-154).
+// One workgroup does forward, loss, backward and the parameter update of every layer: at B = 1 the reference's autograd
+// graph is ~40 ATen launches and a fresh Adam over the hidden layers; here it is one launch.  Limits (host-checked):
+// B <= 16, k <= 64, hidden <= 64, layers <= 8; larger shapes stay on the caller's PyTorch path.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int MLP_MAX_B = 16, MLP_MAX_W = 64, MLP_MAX_L = 8;
+
+enum { MLP_MODE_FORWARD = 0, MLP_MODE_FIT = 1, MLP_MODE_HEDGE = 2 };
+
+struct MlpArgs {
+  float *params;  // packed: per layer W [out, in] row-major, then b [out]
+  const float *bi;     // [B, kp]
+  const float *base;   // [B] logit without the MLP term
+  const float *y;      // [B]
+  float *alpha;        // HEDGE: [L] in/out
+  float *dz_out;       // FIT: [B]
+  float *gbi_out;      // FIT: [B, kp]
+  float *out;          // FORWARD: [B] logit (adam classes) ; FIT: [1] mean loss or null
+  float *layers_out;   // FORWARD: [L, B] sigmoid(base + sum x_l) or null ; HEDGE: [L] losses or null
+  fmx_hyper_t h;       // lr / eps (FIT: rule) ; HEDGE: lr = n
+  float hedge_b, hedge_s;
+  int32_t B, k, kp, hidden, n_layers, mode, rule, loss_kind;
+  float inv_b;
+};
+
+__device__ __forceinline__ int mlp_in(const MlpArgs &a, int l) { return l == 0 ? a.k : a.hidden; }
+__device__ __forceinline__ float *mlp_w(const MlpArgs &a, int l) {
+  size_t off = 0;
+  for (int i = 0; i < l; ++i) off += (size_t)a.hidden * mlp_in(a, i) + a.hidden;
+  return a.params + off;
+}
+
+__global__ __launch_bounds__(256) void k_mlp_small(MlpArgs a) {
+  __shared__ float acts[(MLP_MAX_L + 1) * MLP_MAX_B * MLP_MAX_W];  // x_0 .. x_L, [l][b][j]
+  __shared__ float dA[MLP_MAX_B * MLP_MAX_W], dB[MLP_MAX_B * MLP_MAX_W];  // d x_l (ping-pong); dA is reused as d pre
+  __shared__ float dout[MLP_MAX_L * MLP_MAX_B];  // d loss / d (out_l[b]) per layer (HEDGE) or for the last layer (FIT)
+  __shared__ float lsum[MLP_MAX_L];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int B = a.B, H = a.hidden, L = a.n_layers;
+  auto X = [&](int l, int b, int j) -> float & { return acts[((size_t)l * MLP_MAX_B + b) * MLP_MAX_W + j]; };
+
+  for (int i = tid; i < B * a.k; i += nt) X(0, i / a.k, i % a.k) = a.bi[(size_t)(i / a.k) * a.kp + (i % a.k)];
+  __syncthreads();
+  // ---- forward ----
+  for (int l = 0; l < L; ++l) {
+    const int in = mlp_in(a, l);
+    const float *W = mlp_w(a, l), *bias = W + (size_t)H * in;
+    for (int i = tid; i < B * H; i += nt) {
+      const int b = i / H, j = i % H;
+      float s = bias[j];
+      for (int c = 0; c < in; ++c) s += W[(size_t)j * in + c] * X(l, b, c);
+      X(l + 1, b, j) = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+  }
+  // ---- per-layer outputs, losses and d loss / d out ----
+  if (tid < L) lsum[tid] = 0.f;
+  __syncthreads();
+  if (tid < L * B) {
+    const int l = tid / B, b = tid % B;  // layer l+1's output for sample b
+    const bool need = a.mode == MLP_MODE_HEDGE || l == L - 1 || (a.mode == MLP_MODE_FORWARD && a.layers_out);
+    float g = 0.f;
+    if (need) {
+      float s = 0.f;
+      for (int j = 0; j < H; ++j) s += X(l + 1, b, j);
+      const float z = a.base[b] + s;
+      if (a.mode == MLP_MODE_FORWARD) {
+        if (a.layers_out) a.layers_out[(size_t)l * B + b] = sigmoidf_(z);
+        if (l == L - 1 && a.out) a.out[b] = z;
+      } else if (a.mode == MLP_MODE_FIT) {
+        const float yy = a.y[b];
+        float loss;
+        if (a.loss_kind == FMX_LOSS_BCE_LOGITS) {
+          loss = bcewl(z, yy);
+          g = (sigmoidf_(z) - yy) * a.inv_b;
+        } else {
+          const float p = sigmoidf_(z);
+          loss = bcewl(p, yy);
+          g = (sigmoidf_(p) - yy) * p * (1.f - p) * a.inv_b;
+        }
+        a.dz_out[b] = g;
+        X(0, b, MLP_MAX_W - 1) = loss;  // parked for the ordered sum below (k <= 63 is host-checked in FIT mode)
+      } else {  // HEDGE: BCELoss(sigmoid(z), y), mean over the batch; d/dz = (p - y) / B
+        const float yy = a.y[b];
+        const float p = sigmoidf_(z);
+        const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);
+        X(0, b, MLP_MAX_W - 1 - l) = -(yy * lp + (1.f - yy) * l1p);  // parked per layer
+        g = a.alpha[l] * (p - yy) * a.inv_b;
+      }
+    }
+    dout[l * MLP_MAX_B + b] = g;
+  }
+  __syncthreads();
+  if (a.mode == MLP_MODE_FORWARD) return;
+  if (a.mode == MLP_MODE_FIT) {
+    if (tid == 0 && a.out) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += X(0, b, MLP_MAX_W - 1);
+      a.out[0] = s * a.inv_b;
+    }
+  } else if (tid < L) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += X(0, b, MLP_MAX_W - 1 - tid);
+    lsum[tid] = s * a.inv_b;
+  }
+  // ---- backward + update, top layer first ----
+  float *dcur = dA, *dnext = dB;
+  for (int i = tid; i < B * H; i += nt) dcur[(i / H) * MLP_MAX_W + (i % H)] = dout[(L - 1) * MLP_MAX_B + i / H];
+  __syncthreads();
+  for (int l = L - 1; l >= 0; --l) {
+    const int in = mlp_in(a, l);
+    float *W = mlp_w(a, l), *bias = W + (size_t)H * in;
+    // d pre = d x_{l+1} * (x_{l+1} > 0), in place
+    for (int i = tid; i < B * H; i += nt) {
+      const int b = i / H, j = i % H;
+      if (!(X(l + 1, b, j) > 0.f)) dcur[b * MLP_MAX_W + j] = 0.f;
+    }
+    __syncthreads();
+    // d x_l = W^T d pre (+ this layer's own output gradient in HEDGE mode), with the OLD weights
+    for (int i = tid; i < B * in; i += nt) {
+      const int b = i / in, c = i % in;
+      float s = 0.f;
+      for (int j = 0; j < H; ++j) s += W[(size_t)j * in + c] * dcur[b * MLP_MAX_W + j];
+      if (a.mode == MLP_MODE_HEDGE && l >= 1) s += dout[(l - 1) * MLP_MAX_B + b];
+      dnext[b * MLP_MAX_W + c] = s;
+    }
+    __syncthreads();
+    // parameter gradients (batch summed in sample order) and the update
+    for (int i = tid; i < H * in + H; i += nt) {
+      float g = 0.f;
+      float *p;
+      if (i < H * in) {
+        const int j = i / in, c = i % in;
+        for (int b = 0; b < B; ++b) g += dcur[b * MLP_MAX_W + j] * X(l, b, c);
+        p = W + i;
+      } else {
+        const int j = i - H * in;
+        for (int b = 0; b < B; ++b) g += dcur[b * MLP_MAX_W + j];
+        p = bias + j;
+      }
+      if (a.mode == MLP_MODE_HEDGE || a.rule == FMX_RULE_SGD) *p = *p - a.h.lr * g;
+      else *p = *p - a.h.lr * g * rcp_(fabsf(g) + a.h.eps);
+    }
+    __syncthreads();
+    float *t = dcur;
+    dcur = dnext;
+    dnext = t;
+  }
+  if (a.mode == MLP_MODE_FIT) {
+    for (int i = tid; i < B * a.kp; i += nt) {
+      const int b = i / a.kp, c = i % a.kp;
+      a.gbi_out[i] = c < a.k ? dcur[b * MLP_MAX_W + c] : 0.f;
+    }
+  } else if (tid == 0) {  // Hedge: alpha_i *= b^loss_i, floor s / L, normalise (deepfm_onn.py:147-154)
+    float al[MLP_MAX_L], z = 0.f;
+    for (int i = 0; i < L; ++i) {
+      al[i] = fmaxf(a.alpha[i] * powf(a.hedge_b, lsum[i]), a.hedge_s / (float)L);
+      z += al[i];
+    }
+    for (int i = 0; i < L; ++i) {
+      a.alpha[i] = al[i] / z;
+      if (a.layers_out) a.layers_out[i] = lsum[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_stream_read: HBM-read ceiling probe
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_stream_read(const float4 *buf, int64_t n16, float *sink) {
@@ -1483,6 +1651,74 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
   for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventDestroy(ev[i]);
   delete[] ev;
   return rc;
+}
+
+static int mlp_launch(const fmx_mlp_t *mlp, MlpArgs &a, int32_t B, int32_t kp, fmx_stream_t stream, const char *who) {
+  if (!mlp || !mlp->params) return fail(FMX_ERR_ARG, "%s: null mlp", who);
+  if (mlp->n_layers < 1 || mlp->n_layers > MLP_MAX_L || mlp->hidden < 1 || mlp->hidden > MLP_MAX_W || mlp->k < 1 ||
+      mlp->k > MLP_MAX_W || B < 1 || B > MLP_MAX_B || kp < mlp->k)
+    return fail(FMX_ERR_UNSUPPORTED, "%s: needs B <= %d, k <= %d, hidden <= %d, layers <= %d (got B=%d k=%d hidden=%d layers=%d)", who,
+                MLP_MAX_B, MLP_MAX_W, MLP_MAX_W, MLP_MAX_L, B, mlp->k, mlp->hidden, mlp->n_layers);
+  a.params = mlp->params;
+  a.B = B;
+  a.k = mlp->k;
+  a.kp = kp;
+  a.hidden = mlp->hidden;
+  a.n_layers = mlp->n_layers;
+  hipLaunchKernelGGL(k_mlp_small, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("k_mlp_small");
+}
+
+int fmx_mlp_forward(const fmx_mlp_t *mlp, const float *bi, int32_t kp, const float *base, int32_t B, float *out,
+                    float *layers_out, fmx_stream_t stream) {
+  if (!bi || !base || (!out && !layers_out)) return fail(FMX_ERR_ARG, "fmx_mlp_forward: null argument");
+  MlpArgs a{};
+  a.bi = bi;
+  a.base = base;
+  a.out = out;
+  a.layers_out = layers_out;
+  a.mode = MLP_MODE_FORWARD;
+  return mlp_launch(mlp, a, B, kp, stream, "fmx_mlp_forward");
+}
+
+int fmx_mlp_fit(const fmx_mlp_t *mlp, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind, const float *bi, int32_t kp,
+                const float *base, const float *y, int32_t B, float inv_b, float *dz_out, float *gbi_out, float *loss_out,
+                fmx_stream_t stream) {
+  if (!hyper || !bi || !base || !y || !dz_out || !gbi_out) return fail(FMX_ERR_ARG, "fmx_mlp_fit: null argument");
+  if (rule != FMX_RULE_SIGNADAM && rule != FMX_RULE_SGD) return fail(FMX_ERR_ARG, "fmx_mlp_fit: rule must be SIGNADAM or SGD");
+  if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "fmx_mlp_fit needs a loss");
+  if (mlp && mlp->k > MLP_MAX_W - 1) return fail(FMX_ERR_UNSUPPORTED, "fmx_mlp_fit: k <= %d", MLP_MAX_W - 1);
+  MlpArgs a{};
+  a.bi = bi;
+  a.base = base;
+  a.y = y;
+  a.dz_out = dz_out;
+  a.gbi_out = gbi_out;
+  a.out = loss_out;
+  a.h = *hyper;
+  a.mode = MLP_MODE_FIT;
+  a.rule = rule;
+  a.loss_kind = loss_kind;
+  a.inv_b = inv_b;
+  return mlp_launch(mlp, a, B, kp, stream, "fmx_mlp_fit");
+}
+
+int fmx_mlp_hedge_fit(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge_s, float *alpha, const float *bi, int32_t kp,
+                      const float *base, const float *y, int32_t B, float *losses_out, fmx_stream_t stream) {
+  if (!alpha || !bi || !base || !y) return fail(FMX_ERR_ARG, "fmx_mlp_hedge_fit: null argument");
+  if (mlp && mlp->k + mlp->n_layers > MLP_MAX_W) return fail(FMX_ERR_UNSUPPORTED, "fmx_mlp_hedge_fit: k + layers <= %d", MLP_MAX_W);
+  MlpArgs a{};
+  a.bi = bi;
+  a.base = base;
+  a.y = y;
+  a.alpha = alpha;
+  a.layers_out = losses_out;
+  a.h.lr = lr;
+  a.hedge_b = hedge_b;
+  a.hedge_s = hedge_s;
+  a.mode = MLP_MODE_HEDGE;
+  a.inv_b = 1.0f / (float)B;
+  return mlp_launch(mlp, a, B, kp, stream, "fmx_mlp_hedge_fit");
 }
 
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream) {

@@ -15,7 +15,7 @@ RULES = {"signadam": RULE_SIGNADAM, "sgd": RULE_SGD, "ftrl": RULE_FTRL}
 LOSSES = {None: LOSS_NONE, "none": LOSS_NONE, "logits": LOSS_BCE_LOGITS, "sigmoid": LOSS_BCE_SIGMOID}
 
 EXPORTS = ["fmx_version", "fmx_last_error_string", "fmx_sorted_width", "fmx_sorted_bbits", "fmx_workspace_bytes",
-           "fmx_fm_forward",
+           "fmx_fm_forward", "fmx_mlp_forward", "fmx_mlp_fit", "fmx_mlp_hedge_fit",
            "fmx_sort_occurrences", "fmx_fm_update", "fmx_fm_step", "fmx_fm_stream", "fmx_stream_read"]
 
 
@@ -34,6 +34,11 @@ class Table(C.Structure):
 class Hyper(C.Structure):
     _fields_ = [("lr", C.c_float), ("eps", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
                 ("l1", C.c_float), ("l2", C.c_float)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("n_layers", C.c_int32), ("k", C.c_int32), ("hidden", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class FwdOut(C.Structure):
@@ -65,6 +70,10 @@ def load():
     lib.fmx_fm_step.argtypes = [TP, HP, i32, i32, p, p, p, i32, f32, p, FP, p, p]
     lib.fmx_fm_stream.argtypes = [TP, HP, i32, i32, p, p, i32, i32, f32, i32, p, FP, p, C.POINTER(C.c_float), p]
     lib.fmx_stream_read.argtypes = [p, i64, p, p]
+    MP = C.POINTER(Mlp)
+    lib.fmx_mlp_forward.argtypes = [MP, p, i32, p, i32, p, p, p]
+    lib.fmx_mlp_fit.argtypes = [MP, HP, i32, i32, p, i32, p, p, i32, f32, p, p, p, p]
+    lib.fmx_mlp_hedge_fit.argtypes = [MP, f32, f32, f32, p, p, i32, p, p, i32, p, p]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name == "fmx_workspace_bytes":

@@ -143,6 +143,44 @@ class FMEngine:
                                           self.workspace.data_ptr(), C.byref(out), _ptr(loss_out), ms, self._stream()))
         return None if ms is None else [float(v) for v in ms]
 
+    # ---- the small fused MLP (online steps of DeepFM / NFM / ONN); shapes beyond its limits raise FmxError(UNSUPPORTED) ----
+    MLP_MAX_B, MLP_MAX_W, MLP_MAX_L = 16, 64, 8
+
+    @staticmethod
+    def mlp_fits(B, k, hidden, n_layers, mode):
+        ok = B <= 16 and hidden <= 64 and 1 <= n_layers <= 8
+        if mode == "fit":
+            return ok and k <= 63
+        if mode == "hedge":
+            return ok and k + n_layers <= 64
+        return ok and k <= 64
+
+    def _mlp_struct(self, params, k, hidden, n_layers):
+        return _lib.Mlp(params.data_ptr(), n_layers, k, hidden, 0)
+
+    def mlp_forward(self, params, k, hidden, n_layers, base, B, want_layers):
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        layers = torch.empty((n_layers, B), dtype=torch.float32, device=self.device) if want_layers else None
+        m = self._mlp_struct(params, k, hidden, n_layers)
+        _lib.check(self.lib.fmx_mlp_forward(C.byref(m), self.bi.data_ptr(), self.table.kp, base.data_ptr(), B, out.data_ptr(),
+                                            _ptr(layers), self._stream()))
+        return out, layers
+
+    def mlp_fit(self, params, k, hidden, n_layers, hyper, rule, loss, base, y_d, B, inv_b=None):
+        """-> (dz [B], gbi [B, kp]) for self.update(); the hidden layers in `params` are updated in place."""
+        dz = torch.empty(B, dtype=torch.float32, device=self.device)
+        gbi = torch.empty((B, self.table.kp), dtype=torch.float32, device=self.device)
+        m = self._mlp_struct(params, k, hidden, n_layers)
+        _lib.check(self.lib.fmx_mlp_fit(C.byref(m), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss], self.bi.data_ptr(),
+                                        self.table.kp, base.data_ptr(), y_d.data_ptr(), B, 1.0 / B if inv_b is None else inv_b,
+                                        dz.data_ptr(), gbi.data_ptr(), self.loss_out.data_ptr(), self._stream()))
+        return dz, gbi
+
+    def mlp_hedge_fit(self, params, k, hidden, n_layers, lr, hedge_b, hedge_s, alpha, base, y_d, B):
+        m = self._mlp_struct(params, k, hidden, n_layers)
+        _lib.check(self.lib.fmx_mlp_hedge_fit(C.byref(m), lr, hedge_b, hedge_s, alpha.data_ptr(), self.bi.data_ptr(),
+                                              self.table.kp, base.data_ptr(), y_d.data_ptr(), B, None, self._stream()))
+
     def check_error_flag(self):
         if int(self.error.item()) != 0:
             self.error.zero_()

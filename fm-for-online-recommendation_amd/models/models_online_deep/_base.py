@@ -91,6 +91,15 @@ class OnlineFMBase(nn.Module):
             for _ in range(num_hidden_layers - 1):
                 layers.append(nn.Linear(neuron_per_hidden_layer, neuron_per_hidden_layer))
             self.hidden_layers = nn.ModuleList(layers).to(self.device)
+            # one flat buffer behind every hidden parameter (W_0, b_0, W_1, b_1, ...): the fused MLP kernel updates it in
+            # place and the nn.Linear modules (state_dict, the PyTorch path for large shapes) see the same memory
+            flat = torch.cat([p.detach().reshape(-1) for layer in self.hidden_layers for p in (layer.weight, layer.bias)])
+            self._mlp_flat = flat.contiguous()
+            off = 0
+            for layer in self.hidden_layers:
+                for p in (layer.weight, layer.bias):
+                    p.data = self._mlp_flat[off:off + p.numel()].view(p.shape)
+                    off += p.numel()
         if self._onn:
             # a plain device tensor (on a GPU the reference's Parameter(...).to(device) is one too)
             self.alpha = torch.full((num_hidden_layers,), 1 / (num_hidden_layers + 1), dtype=torch.float32,
@@ -217,6 +226,10 @@ class OnlineFMBase(nn.Module):
         with torch.no_grad():
             if not self._has_mlp:
                 return e.logit[:B].clone()
+            if e.mlp_fits(B, self.embedding_size, self.neuron_per_hidden_layer, self.num_hidden_layers, "forward"):
+                out, layers = e.mlp_forward(self._mlp_flat, self.embedding_size, self.neuron_per_hidden_layer,
+                                            self.num_hidden_layers, self._base_logit(B).contiguous(), B, self._onn)
+                return (layers[-1], layers) if self._onn else out
             acts = self._mlp(e.bi[:B, :self.embedding_size])
             base = self._base_logit(B)
             if not self._onn:
@@ -253,6 +266,13 @@ class OnlineFMBase(nn.Module):
         e, k = self._engine, self.embedding_size
         e.sort(idx_d)
         B = e.forward(self._hyper, idx_d, xv_d)
+        if self.update_rule != "ftrl" and e.mlp_fits(B, k, self.neuron_per_hidden_layer, self.num_hidden_layers, "fit"):
+            # one launch: MLP forward, loss, backward, fresh-Adam update of the hidden layers; then the table update
+            dz, gbi = e.mlp_fit(self._mlp_flat, k, self.neuron_per_hidden_layer, self.num_hidden_layers, self._hyper,
+                                self.update_rule, self._loss_fit, self._base_logit(B).contiguous(), y_d, B)
+            e.update(self._hyper, self.update_rule, B, xv_d, dz, dz if self._fm_term_in_forward else None, gbi,
+                     with_loss=False)
+            return
         bi = e.bi[:B, :k].detach().clone().requires_grad_(True)
         base = self._base_logit(B).detach().clone().requires_grad_(True)
         for p in self.hidden_layers.parameters():
@@ -283,6 +303,10 @@ class OnlineFMBase(nn.Module):
             raise RuntimeError(f"shape '[{self.batch_size}]' is invalid for input of size {B}")
         e, k = self._engine, self.embedding_size
         e.forward(self._hyper, idx_d, xv_d, want_first=False)
+        if e.mlp_fits(B, k, self.neuron_per_hidden_layer, self.num_hidden_layers, "hedge"):
+            e.mlp_hedge_fit(self._mlp_flat, k, self.neuron_per_hidden_layer, self.num_hidden_layers, float(self.n),
+                            float(self.b), float(self.s), self.alpha, self._base_logit(B).contiguous(), y_d, B)
+            return
         base = self._base_logit(B).detach()
         for p in self.hidden_layers.parameters():
             p.grad = None

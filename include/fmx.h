@@ -173,6 +173,35 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
                   int32_t n_steps, void *workspace, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
                   fmx_stream_t stream);
 
+/* ---- the small relu MLP on top of the bi-interaction vector (online steps of DeepFM / NFM and the ONN classes) ----
+ * params: per layer W [out, in] row-major then b [out]; layer 0 maps k -> hidden, the others hidden -> hidden; the network's
+ * contribution to the logit is the sum of the last activation (reference deepfm_adam.py:82-88: there is no output layer).
+ * One workgroup per call; limits B <= 16, k <= 64 (63 for fit), hidden <= 64, layers <= 8, else FMX_ERR_UNSUPPORTED (larger
+ * shapes stay on the caller's PyTorch path). */
+typedef struct fmx_mlp {
+  float *params;
+  int32_t n_layers, k, hidden, reserved;
+} fmx_mlp_t;
+
+/* out [B] = base + sum_j x_L[j]  (may be null) ; layers_out [L, B] = sigmoid(base + sum_j x_l[j]) (may be null).
+ * Replaces: the MLP part of forward() (reference deepfm_adam.py:79-89, deepfm_onn.py:88-102). */
+int fmx_mlp_forward(const fmx_mlp_t *mlp, const float *bi, int32_t kp, const float *base, int32_t B, float *out,
+                    float *layers_out, fmx_stream_t stream);
+
+/* Forward, loss (fmx_loss on base + MLP), backward and the update of every hidden layer under `rule`
+ * (FMX_RULE_SIGNADAM = the reference's fresh Adam, or FMX_RULE_SGD); emits what fmx_fm_update needs for the tables:
+ * dz_out [B] = dL/dlogit and gbi_out [B, kp] = dL/dbi through the MLP.  loss_out [1] = mean loss (may be null).
+ * Replaces: DeepFMAdam.fit / NFMAdam.fit minus the table part (reference deepfm_adam.py:106-119, nfm_adam.py:105-118). */
+int fmx_mlp_fit(const fmx_mlp_t *mlp, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind, const float *bi, int32_t kp,
+                const float *base, const float *y, int32_t B, float inv_b, float *dz_out, float *gbi_out, float *loss_out,
+                fmx_stream_t stream);
+
+/* Hedge backprop (reference deepfm_onn.py:109-154): per-layer BCELoss(sigmoid(base + sum x_l), y), hidden layers updated by
+ * lr * sum_{i >= j} alpha_i dloss_i/dlayer_j, then alpha_i <- max(alpha_i * hedge_b^loss_i, hedge_s / L) normalised.
+ * alpha [L] is updated in place; losses_out [L] may be null.  The tables are not touched (as in the reference). */
+int fmx_mlp_hedge_fit(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge_s, float *alpha, const float *bi, int32_t kp,
+                      const float *base, const float *y, int32_t B, float *losses_out, fmx_stream_t stream);
+
 /* Streaming read of `bytes` (multiple of 16) with 16-byte loads; sink [1] receives a checksum so the loads stay
  * live.  Used by bench.py to measure the HBM-read ceiling on the same GPU in the same run. */
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream);

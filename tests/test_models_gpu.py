@@ -197,3 +197,26 @@ def test_extension_rules_vs_oracle(rule):
     assert_close(Vh, V1, tol, 3e-7 * np.abs(V1).max(), "V")
     assert_close(wh, w1, tol, 3e-7 * np.abs(w1).max(), "w")
     assert_close(sd["bias"], b1, tol, 1e-7, "bias")
+
+
+@pytest.mark.parametrize("name", ["DeepFMAdam", "NFMAdam", "DeepFMOnn", "NFMOnn"])
+def test_fused_mlp_kernel_equals_pytorch_path(name, monkeypatch):
+    """Shapes within the fused MLP kernel's limits go through k_mlp_small, larger ones through PyTorch autograd: both
+    must give the same step (checked by forcing the PyTorch path on the same inputs)."""
+    import fmx
+    z, meta = load_model_fixture(name, "criteo39s")
+    B = meta["B2"]
+    Xi, Xv, Y = z["A/Xi2"].tolist(), z["A/Xv2"].tolist(), z["A/Y2"].tolist()
+    results = []
+    for force_torch in (False, True):
+        m = build(name, meta, B)
+        m.load_state_dict(sub(z, "A/sd0"))
+        if force_torch:
+            monkeypatch.setattr(fmx.FMEngine, "mlp_fits", staticmethod(lambda *a, **k: False))
+        out = m.forward(Xi, Xv)
+        out = out[1] if isinstance(out, tuple) else out
+        m.fit(Xi, Xv, Y)
+        results.append((out.cpu().numpy(), sd_np(m)))
+        monkeypatch.undo()
+    assert_close(results[0][0], results[1][0], 1e-5, 1e-6, "forward")
+    assert_state_close(results[0][1], results[1][1], sub(z, "A/sd0"), what="fit: kernel vs pytorch")
