@@ -955,7 +955,10 @@ __global__ __launch_bounds__(256) void k_mlp_small(MlpArgs a) {
         const float p = sigmoidf_(z);
         const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);
         X(0, b, MLP_MAX_W - 1 - l) = -(yy * lp + (1.f - yy) * l1p);  // parked per layer
-        g = a.alpha[l] * (p - yy) * a.inv_b;
+        // autograd through nn.BCELoss then sigmoid: (p - y) / max(p (1 - p), 1e-12) * p (1 - p) -- NOT (p - y) once p
+        // saturates (p == 1.0f gives exactly 0, as in the reference)
+        const float pq = p * (1.f - p);
+        g = a.alpha[l] * ((p - yy) / fmaxf(pq, 1e-12f)) * pq * a.inv_b;
       }
     }
     dout[l * MLP_MAX_B + b] = g;

@@ -305,7 +305,7 @@ class OnlineFMBase(nn.Module):
         e.forward(self._hyper, idx_d, xv_d, want_first=False)
         if e.mlp_fits(B, k, self.neuron_per_hidden_layer, self.num_hidden_layers, "hedge"):
             e.mlp_hedge_fit(self._mlp_flat, k, self.neuron_per_hidden_layer, self.num_hidden_layers, float(self.n),
-                            float(self.b), float(self.s), self.alpha, self._base_logit(B).contiguous(), y_d, B)
+                            float(self.b.detach()), float(self.s.detach()), self.alpha, self._base_logit(B).contiguous(), y_d, B)
             return
         base = self._base_logit(B).detach()
         for p in self.hidden_layers.parameters():
