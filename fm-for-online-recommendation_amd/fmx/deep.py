@@ -1,0 +1,107 @@
+"""Online DeepFM / NFM mini-batch step on device tensors, data-parallel over the GPUs of one node
+(BASELINE.json configs[3]: bi-interaction + 3 x 256 relu MLP, SGD, RCCL all-reduce of the dense gradients).
+
+Per step and rank (B local samples, G ranks, everything scaled by 1 / (G B) so that the result is the G B-sample step):
+  1. forward of the tables on the local slice (k_fm_forward): S, bi, FM logit
+  2. the MLP on bi (PyTorch: at 3 x 256 it is a plain GEMM chain; a fused kernel exists only for the small online
+     shapes, fmx_mlp_fit) -> loss, dL/dlogit, dL/dbi, local MLP gradients
+  3. ONE fused all-reduce (sum) of the flattened MLP gradients            -- the dense exchange
+  4. all-gather of the low-rank factors of the row gradients (idx, S, dz, dL/dbi)  -- 288 B per sample, no rows move
+  5. identical sort + row-reduced table update on every replica (k_sort_occ, k_fm_update, k_fm_fixup), SGD on the MLP
+Replicas stay bit-identical in the tables (deterministic kernels) and equal in the MLP up to the all-reduce's own
+summation order.  The compute behind the table is a small backend interface (HIP in the product; tests inject an
+oracle-backed one to exercise this logic on CPU with gloo).
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+class HipDeepBackend:
+    def __init__(self, engine, hyper, rule):
+        self.e, self.hyper, self.rule = engine, hyper, rule
+
+    def forward(self, idx):
+        """-> (S [B,kp], bi [B,kp], sfirst [B], logit_fm [B]) views valid until the next forward."""
+        B = self.e.forward(self.hyper, idx, None, want_first=False, want_bi=True)
+        e = self.e
+        return e.S[:B], e.bi[:B], e.sfirst[:B], e.logit[:B]
+
+    def bias(self):
+        return self.e.table.bias_weight()
+
+    def update(self, idx_g, S_g, dz_g, gbi_g, fm_term, inv_b):
+        e = self.e
+        GB = idx_g.shape[0]
+        e._ensure(GB)
+        e.sort(idx_g)
+        e.update(self.hyper, self.rule, GB, None, dz_g, dz_g if fm_term else None, gbi_g, inv_b=inv_b, with_loss=False, S=S_g)
+
+
+class DeepFMTrainer:
+    def __init__(self, backend, hidden_layers, k, kp, mlp_lr, fm_term=True, loss="logits", group=None):
+        """hidden_layers: list of nn.Linear on the device (k -> H -> ... -> H); the network's logit contribution is the
+        sum of the last activation (reference deepfm_adam.py:82-88).  fm_term=False gives NFM (nfm_adam.py:78-88)."""
+        self.backend, self.layers, self.k, self.kp = backend, list(hidden_layers), k, kp
+        self.mlp_lr, self.fm_term, self.loss, self.group = mlp_lr, fm_term, loss, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.params = [p for layer in self.layers for p in (layer.weight, layer.bias)]
+        self._bufs = {}
+
+    def _gathered(self, name, local):
+        if self.world == 1:
+            return local
+        shape = (self.world * local.shape[0],) + tuple(local.shape[1:])
+        key = (name, shape, local.dtype, local.device)
+        out = self._bufs.get(key)
+        if out is None:
+            out = self._bufs[key] = torch.empty(shape, dtype=local.dtype, device=local.device)
+        if local.is_cuda and dist.get_backend(self.group) == "gloo":     # rehearsal on a shared GPU only
+            host = torch.empty(shape, dtype=local.dtype)
+            dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        return out
+
+    def step(self, idx_local, y_local):
+        """One exact data-parallel step; returns this rank's share of the global mean loss (sum over ranks = the loss)."""
+        B = idx_local.shape[0]
+        inv_b = 1.0 / (B * self.world)
+        idx_g = self._gathered("idx", idx_local)
+        S, bi, sfirst, logit_fm = self.backend.forward(idx_local)
+        bi_leaf = bi[:, :self.k].detach().clone().requires_grad_(True)
+        base = (logit_fm if self.fm_term else sfirst + self.backend.bias()).detach().clone().requires_grad_(True)
+        for p in self.params:
+            p.grad = None
+        x = bi_leaf
+        for layer in self.layers:
+            x = F.relu(layer(x))
+        out = base + x.sum(1)
+        z = torch.sigmoid(out) if self.loss == "sigmoid" else out
+        loss = F.binary_cross_entropy_with_logits(z, y_local, reduction="sum") * inv_b
+        loss.backward()
+        # ---- the dense exchange: one bucket ----
+        flat = torch.cat([p.grad.reshape(-1) for p in self.params])
+        if self.world > 1:
+            if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+                host = flat.cpu()
+                dist.all_reduce(host, group=self.group)
+                flat = host.to(flat.device)
+            else:
+                dist.all_reduce(flat, group=self.group)
+        # ---- the sparse exchange: low-rank factors only ----
+        gbi = bi_leaf.grad
+        if self.k != self.kp:
+            gbi = F.pad(gbi, (0, self.kp - self.k))
+        S_g = self._gathered("S", S)
+        dz_g = self._gathered("dz", base.grad)
+        gbi_g = self._gathered("gbi", gbi.contiguous())
+        self.backend.update(idx_g, S_g.contiguous(), dz_g.contiguous(), gbi_g, self.fm_term, inv_b)
+        with torch.no_grad():
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                p -= self.mlp_lr * flat[off:off + n].view_as(p)
+                off += n
+        return loss.detach()

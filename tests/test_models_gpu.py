@@ -220,3 +220,45 @@ def test_fused_mlp_kernel_equals_pytorch_path(name, monkeypatch):
         monkeypatch.undo()
     assert_close(results[0][0], results[1][0], 1e-5, 1e-6, "forward")
     assert_state_close(results[0][1], results[1][1], sub(z, "A/sd0"), what="fit: kernel vs pytorch")
+
+
+@pytest.mark.parametrize("name", ["DeepFMAdam", "NFMAdam"])
+def test_deep_trainer_step_vs_oracle(name):
+    """fmx.DeepFMTrainer (device tensors, PyTorch MLP, world size 1) against the oracle's class step under SGD."""
+    import fmx
+    import torch.nn as nn
+    z, meta = load_model_fixture(name, "criteo39s")
+    sd0 = sub(z, "A/sd0")
+    sizes, k, L, H, lr = meta["feature_sizes"], meta["k"], meta["L"], meta["H"], meta["n"]
+    table = fmx.FlatTable(sizes, k, layout="weights")
+    F_ = len(sizes)
+    table.load_reference([sd0[f"first_order_embeddings.{i}.weight"] for i in range(F_)],
+                         [sd0[f"second_order_embeddings.{i}.weight"] for i in range(F_)])
+    table.set_bias_weight(float(sd0["bias"]))
+    eng = fmx.FMEngine(table, max_batch=64)
+    layers = [nn.Linear(k if j == 0 else H, H).cuda() for j in range(L)]
+    with torch.no_grad():
+        for j, layer in enumerate(layers):
+            layer.weight.copy_(torch.from_numpy(sd0[f"hidden_layers.{j}.weight"]))
+            layer.bias.copy_(torch.from_numpy(sd0[f"hidden_layers.{j}.bias"]))
+    hyper = fmx.Hyper(lr=lr)
+    loss_kind = orc.LOSS_KIND[(name, "fit")]
+    tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, hyper, "sgd"), layers, k, table.kp, mlp_lr=lr,
+                           fm_term=(name == "DeepFMAdam"), loss=loss_kind)
+    Xi, Y = z["A/Xi1"], z["A/Y1"]                     # Xv == 1
+    idx_d, _, y_d = eng.to_device(Xi.astype(np.int32), None, Y)
+    tr.step(idx_d, y_d)
+    torch.cuda.synchronize()
+    om = orc.OracleModel(name, sd0, update_rule="sgd")
+    om.fit(Xi, z["A/Xv1"], Y)
+    ref = om.state_dict()
+    first, second = table.export_reference()
+    got = {"bias": table.bias_weight().cpu().numpy()}
+    for i in range(F_):
+        got[f"first_order_embeddings.{i}.weight"] = first[i].numpy()
+        got[f"second_order_embeddings.{i}.weight"] = second[i].numpy()
+    for j, layer in enumerate(layers):
+        got[f"hidden_layers.{j}.weight"] = layer.weight.detach().cpu().numpy()
+        got[f"hidden_layers.{j}.bias"] = layer.bias.detach().cpu().numpy()
+    ref = {kk: v for kk, v in ref.items() if kk in got}
+    assert_state_close(got, ref, {kk: sd0[kk] for kk in ref}, what=f"{name} sgd step")
