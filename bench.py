@@ -79,6 +79,65 @@ def cpu_baseline(idx_pool, y_pool, sizes, seconds=15.0):
                 sample=f"{n} steps of B={idx_pool.shape[1]} of the same synthetic stream through {impl}")
 
 
+def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
+    """BASELINE configs[3]: online DeepFM (bi-interaction + 3 x 256 relu MLP, SGD lr 1e-3) on the same synthetic Criteo
+    stream, exact data parallelism (fmx.DeepFMTrainer).  The MLP runs in PyTorch (rocBLAS GEMMs) this round."""
+    import torch.nn as nn
+    lr, hidden, n_layers = 1e-3, 256, 3
+    table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="weights", device=dev)
+    g = torch.Generator(device=dev).manual_seed(SEED)
+    table.rows[:, :K_EMB] = torch.randn((table.n_rows, K_EMB), generator=g, device=dev) * 0.01
+    torch.manual_seed(SEED)                                   # identical MLP replicas on every rank
+    layers = [nn.Linear(K_EMB if j == 0 else hidden, hidden).to(dev) for j in range(n_layers)]
+    eng = fmx.FMEngine(table, max_batch=BATCH * world)
+    tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=lr), "sgd"), layers, K_EMB, table.kp, mlp_lr=lr)
+    idx_np, y_np = synth_pool(N_POOL, BATCH, CRITEO_SIZES, SEED + 1000 * rank, zipf=args.zipf)
+    idx_pool, y_pool = torch.from_numpy(idx_np).to(dev), torch.from_numpy(y_np).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(n, first=0):
+        out = None
+        for s in range(n):
+            out = tr.step(idx_pool[(first + s) % N_POOL], y_pool[(first + s) % N_POOL])
+        return out
+    steps, warm = min(args.steps, 100), min(args.warmup, 10)
+    run(warm)
+    barrier()
+    t0 = time.perf_counter()
+    last = run(steps, warm)
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.check_error_flag()
+    loss = last.clone()
+    if world > 1:
+        tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+        ll = loss.cpu() if rehearsal else loss
+        dist.all_reduce(ll)
+        loss = ll
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    mlp_params = sum(p.numel() for layer in layers for p in layer.parameters())
+    print(json.dumps({
+        "metric": "samples/sec online-DeepFM (Criteo-39-field, k=16, 3x256 relu MLP) SGD", "value": steps * BATCH * world / dt,
+        "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "online DeepFM fwd+bwd, fused SGD row update of the tables, PyTorch MLP 16-256-256-256 "
+                               f"({mlp_params} parameters, {mlp_params * 4} B all-reduced per step when N > 1), synthetic "
+                               f"Criteo-39 (R=1,006,628, k=16, B={BATCH} per GPU); BASELINE.json configs[3]",
+                   "global_batch": BATCH * world,
+                   "parallelism": "1 GPU" if world == 1 else f"dp{world}: all-gather of (idx, S, dz, dL/dbi) + one all-reduce "
+                                                             "of the MLP gradients (exact)"},
+        "final_loss": float(loss)}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +146,9 @@ def main():
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05) indices instead of uniform (secondary workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--row-stride", type=int, default=0)
+    ap.add_argument("--workload", default="fm", choices=["fm", "deepfm"],
+                    help="fm: the headline metric (BASELINE configs[1]+[2]); deepfm: configs[3], bi-interaction + 3x256 relu "
+                         "MLP, SGD, data-parallel with one fused all-reduce of the dense gradients")
     ap.add_argument("--rule", default="ftrl", choices=["ftrl", "sgd", "signadam"],
                     help="update rule (the headline metric is ftrl; the others are for kernel comparisons)")
     args = ap.parse_args()
@@ -115,6 +177,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     # ---- resident state: FTRL table (z, n) with V ~ N(0, 0.01) folded into z, first-order weights 0 ----
+    if args.workload == "deepfm":
+        return bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal)
     RULE = args.rule
     table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="ftrl" if RULE == "ftrl" else "weights", device=dev,
                           row_stride=args.row_stride if args.row_stride else None, ftrl=HYPER)

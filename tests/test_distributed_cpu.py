@@ -114,3 +114,92 @@ def test_two_ranks_equal_one_rank():
             np.testing.assert_array_equal(state[k], np.asarray(st[k]), err_msg=f"rank {rank} {k}")   # bit-identical
     for k in st:
         np.testing.assert_array_equal(res[0][2][k], res[1][2][k])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DeepFM: exact table data parallelism + one fused all-reduce of the dense (MLP) gradients
+# ---------------------------------------------------------------------------------------------------------
+class OracleDeepBackend:
+    """Test stand-in for fmx.HipDeepBackend (weights layout, SGD rule on the tables)."""
+
+    def __init__(self, V, w, bias, offs, lr):
+        self.V, self.w, self.b, self.offs, self.lr = V, w, np.float32(bias), offs, lr
+
+    def forward(self, idx):
+        rows = idx.numpy().astype(np.int64) + self.offs[None, :]
+        fw = orc.flat_forward(self.V, self.w, self.b, rows, np.ones(rows.shape, dtype=np.float32))
+        return (torch.from_numpy(fw["S"]), torch.from_numpy(fw["bi"]), torch.from_numpy(fw["sfirst"]),
+                torch.from_numpy(fw["logit"]))
+
+    def bias(self):
+        return torch.tensor(float(self.b))
+
+    def update(self, idx_g, S_g, dz_g, gbi_g, fm_term, inv_b):
+        rows = idx_g.numpy().astype(np.int64) + self.offs[None, :]
+        dz, gbi = dz_g.numpy(), gbi_g.numpy()[:, :self.V.shape[1]]
+        G = (gbi + dz[:, None]).astype(np.float32) if fm_term else gbi.astype(np.float32)
+        u, dV, dw = orc.flat_row_gradients(self.V, rows, np.ones(rows.shape, dtype=np.float32), S_g.numpy(), dz, G)
+        self.V[u] = orc.sgd_step(self.V[u], dV, self.lr)
+        self.w[u] = orc.sgd_step(self.w[u], dw, self.lr)
+        self.b = orc.sgd_step(self.b, dz.sum(dtype=np.float32), self.lr)
+
+
+def _make_deep(world):
+    import fmx
+    import torch.nn as nn
+    rng = np.random.default_rng(4)
+    offs = np.concatenate([[0], np.cumsum(SIZES)]).astype(np.int64)
+    R = int(offs[-1])
+    V = (rng.normal(size=(R, K)) * 0.3).astype(np.float32)
+    w = (rng.normal(size=R) * 0.3).astype(np.float32)
+    be = OracleDeepBackend(V, w, 0.2, offs[:-1], lr=0.05)
+    torch.manual_seed(7)
+    layers = [nn.Linear(K, 12), nn.Linear(12, 12)]
+    return be, layers, fmx.DeepFMTrainer(be, layers, K, K, mlp_lr=0.05, fm_term=True, loss="logits")
+
+
+def _deep_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    be, layers, tr = _make_deep(world)
+    losses = []
+    for idx, y in make_batches(world):
+        sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL)
+        l = tr.step(torch.from_numpy(idx[sl]), torch.from_numpy(y[sl])).clone()
+        dist.all_reduce(l)
+        losses.append(float(l))
+    q.put((rank, losses, be.V.copy(), be.w.copy(), float(be.b), [p.detach().numpy().copy() for l_ in layers for p in l_.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_deepfm_two_ranks_equal_one_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_deep_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.set_num_threads(1)
+    be, layers, tr = _make_deep(1)
+    ref_losses = [float(tr.step(torch.from_numpy(idx), torch.from_numpy(y))) for idx, y in make_batches(world)]
+    ref_params = [p.detach().numpy() for l_ in layers for p in l_.parameters()]
+    for rank, losses, V, w, b, params in res:
+        np.testing.assert_allclose(losses, ref_losses, rtol=2e-6)
+        np.testing.assert_allclose(V, be.V, rtol=1e-5, atol=1e-7)       # dz / gbi come from per-rank GEMMs: not bitwise
+        np.testing.assert_allclose(w, be.w, rtol=1e-5, atol=1e-7)
+        assert abs(b - float(be.b)) <= 1e-6
+        for a, r in zip(params, ref_params):
+            np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-7)
+    # the two replicas of the 2-rank run are identical to each other, bit for bit
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+    for a, b_ in zip(res[0][5], res[1][5]):
+        np.testing.assert_array_equal(a, b_)
