@@ -39,11 +39,12 @@ class HipDeepBackend:
 
 
 class DeepFMTrainer:
-    def __init__(self, backend, hidden_layers, k, kp, mlp_lr, fm_term=True, loss="logits", group=None):
+    def __init__(self, backend, hidden_layers, k, kp, mlp_lr, fm_term=True, loss="logits", group=None, use_graph=False):
         """hidden_layers: list of nn.Linear on the device (k -> H -> ... -> H); the network's logit contribution is the
         sum of the last activation (reference deepfm_adam.py:82-88).  fm_term=False gives NFM (nfm_adam.py:78-88)."""
         self.backend, self.layers, self.k, self.kp = backend, list(hidden_layers), k, kp
         self.mlp_lr, self.fm_term, self.loss, self.group = mlp_lr, fm_term, loss, group
+        self.use_graph = use_graph      # replay the MLP section as a captured graph (static batch size)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = [p for layer in self.layers for p in (layer.weight, layer.bias)]
         self._bufs = {}
@@ -64,14 +65,11 @@ class DeepFMTrainer:
             dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         return out
 
-    def step(self, idx_local, y_local):
-        """One exact data-parallel step; returns this rank's share of the global mean loss (sum over ranks = the loss)."""
-        B = idx_local.shape[0]
-        inv_b = 1.0 / (B * self.world)
-        idx_g = self._gathered("idx", idx_local)
-        S, bi, sfirst, logit_fm = self.backend.forward(idx_local)
-        bi_leaf = bi[:, :self.k].detach().clone().requires_grad_(True)
-        base = (logit_fm if self.fm_term else sfirst + self.backend.bias()).detach().clone().requires_grad_(True)
+    # ---- the MLP section (forward, loss, backward) -- optionally captured once into a graph and replayed: at 3 x 256 the
+    #      ~40 small PyTorch launches cost more host time than the GEMMs take on the GPU ----
+    def _mlp_section(self, bi_in, base_in, y_in, inv_b):
+        bi_leaf = bi_in.detach().clone().requires_grad_(True)
+        base = base_in.detach().clone().requires_grad_(True)
         for p in self.params:
             p.grad = None
         x = bi_leaf
@@ -79,10 +77,47 @@ class DeepFMTrainer:
             x = F.relu(layer(x))
         out = base + x.sum(1)
         z = torch.sigmoid(out) if self.loss == "sigmoid" else out
-        loss = F.binary_cross_entropy_with_logits(z, y_local, reduction="sum") * inv_b
+        loss = F.binary_cross_entropy_with_logits(z, y_in, reduction="sum") * inv_b
         loss.backward()
-        # ---- the dense exchange: one bucket ----
         flat = torch.cat([p.grad.reshape(-1) for p in self.params])
+        gbi = bi_leaf.grad
+        if self.k != self.kp:
+            gbi = F.pad(gbi, (0, self.kp - self.k))
+        return loss.detach(), base.grad.contiguous(), gbi.contiguous(), flat
+
+    def _mlp_section_graphed(self, bi_in, base_in, y_in, inv_b):
+        key = (bi_in.shape[0], inv_b)
+        if getattr(self, "_graph_key", None) != key:
+            B = bi_in.shape[0]
+            dev = bi_in.device
+            self._g_in = (torch.empty((B, self.k), device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev))
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                       # warm-up outside the capture (allocator, rocBLAS handles)
+                for src, dst in zip((bi_in, base_in, y_in), self._g_in):
+                    dst.copy_(src)
+                for _ in range(2):
+                    self._mlp_section(*self._g_in, inv_b)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._g_out = self._mlp_section(*self._g_in, inv_b)
+            self._graph_key = key
+        for src, dst in zip((bi_in, base_in, y_in), self._g_in):
+            dst.copy_(src)
+        self._graph.replay()
+        return self._g_out
+
+    def step(self, idx_local, y_local):
+        """One exact data-parallel step; returns this rank's share of the global mean loss (sum over ranks = the loss)."""
+        B = idx_local.shape[0]
+        inv_b = 1.0 / (B * self.world)
+        idx_g = self._gathered("idx", idx_local)
+        S, bi, sfirst, logit_fm = self.backend.forward(idx_local)
+        base_in = logit_fm if self.fm_term else sfirst + self.backend.bias()
+        section = self._mlp_section_graphed if (self.use_graph and bi.is_cuda) else self._mlp_section
+        loss, dz, gbi, flat = section(bi[:, :self.k], base_in, y_local, inv_b)
+        # ---- the dense exchange: one bucket ----
         if self.world > 1:
             if flat.is_cuda and dist.get_backend(self.group) == "gloo":
                 host = flat.cpu()
@@ -91,12 +126,9 @@ class DeepFMTrainer:
             else:
                 dist.all_reduce(flat, group=self.group)
         # ---- the sparse exchange: low-rank factors only ----
-        gbi = bi_leaf.grad
-        if self.k != self.kp:
-            gbi = F.pad(gbi, (0, self.kp - self.k))
         S_g = self._gathered("S", S)
-        dz_g = self._gathered("dz", base.grad)
-        gbi_g = self._gathered("gbi", gbi.contiguous())
+        dz_g = self._gathered("dz", dz)
+        gbi_g = self._gathered("gbi", gbi)
         self.backend.update(idx_g, S_g.contiguous(), dz_g.contiguous(), gbi_g, self.fm_term, inv_b)
         with torch.no_grad():
             off = 0
@@ -104,4 +136,4 @@ class DeepFMTrainer:
                 n = p.numel()
                 p -= self.mlp_lr * flat[off:off + n].view_as(p)
                 off += n
-        return loss.detach()
+        return loss

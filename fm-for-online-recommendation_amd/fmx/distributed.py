@@ -16,23 +16,51 @@ import torch
 import torch.distributed as dist
 
 
+def max_step_batch(max_field_rows):
+    """Largest batch one exact step can take: the occurrence sort packs (local index, sample) into 32 bits and sorts a
+    field inside one workgroup's LDS (include/fmx.h), so  (max_field_rows - 1) < (0xFFFFFFFF >> log2(batch))  and
+    batch <= 32768."""
+    bbits = 15
+    while bbits > 6 and (max_field_rows - 1) >= (0xFFFFFFFF >> bbits):
+        bbits -= 1
+    return 1 << bbits
+
+
 class HipBackend:
     """The product backend: fmx.FMEngine on this rank's GPU."""
 
     def __init__(self, engine, hyper, rule, loss):
         self.e, self.hyper, self.rule, self.loss = engine, hyper, rule, loss
+        self.max_global_batch = max_step_batch(max(engine.table.feature_sizes))
 
     def forward(self, idx, y, inv_b):
         """-> (S [B,kp], dz [B], loss_b [B]) views valid until the next forward."""
         B = self.e.forward(self.hyper, idx, None, y, loss=self.loss, inv_b=inv_b, want_first=False, want_bi=False)
         return self.e.S[:B], self.e.dz[:B], self.e.loss_b[:B]
 
+    def start_sort(self, idx_g):
+        """The global occurrence sort only needs the gathered indices: it runs on a side stream while this rank's
+        forward pass and the S / dlogit gathers proceed."""
+        e = self.e
+        e._ensure(idx_g.shape[0])
+        cur = torch.cuda.current_stream(e.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=e.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            e.sort(idx_g)
+        self._sorted_for = idx_g.data_ptr()
+
     def update(self, idx_g, S_g, dz_g, loss_g, inv_b):
-        """Sort + row-reduced update over the global batch; returns the mean-loss tensor [1] (no sync)."""
+        """Row-reduced update over the global batch (sorted by start_sort, or here); returns the mean-loss tensor [1]."""
         e = self.e
         GB = idx_g.shape[0]
         e._ensure(GB)
-        e.sort(idx_g)
+        if getattr(self, "_sorted_for", None) == idx_g.data_ptr() and getattr(self, "_side", None) is not None:
+            torch.cuda.current_stream(e.device).wait_stream(self._side)
+        else:
+            e.sort(idx_g)
+        self._sorted_for = None
         e.update(self.hyper, self.rule, GB, None, dz_g, dz_g, None, inv_b=inv_b, with_loss=True, S=S_g, loss_b=loss_g)
         return e.loss_out
 
@@ -65,10 +93,30 @@ class DataParallelFM:
 
     def step(self, idx_local, y_local):
         """One exact data-parallel step.  idx_local [B,F] int32 and y_local [B] fp32 are this rank's slice; the global
-        batch is the rank-major concatenation.  Returns the global mean-loss tensor [1]."""
+        batch is the rank-major concatenation.  Returns the global mean-loss tensor [1] (of the last sub-step, see below).
+
+        When G * B exceeds what one exact step can take (backend.max_global_batch: 16,384 for the Criteo vocabulary,
+        whose largest field needs 18 index bits), the batch is processed as consecutive exact steps over equal slices of
+        every rank's samples -- still exact online learning, with a smaller global batch per update."""
+        B = idx_local.shape[0]
+        cap = getattr(self.backend, "max_global_batch", None)
+        n_sub = 1
+        while cap is not None and (B // n_sub) * self.world > cap and (B // n_sub) % 2 == 0:
+            n_sub *= 2
+        if n_sub > 1:
+            out = None
+            Bs = B // n_sub
+            for j in range(n_sub):
+                out = self._step(idx_local[j * Bs:(j + 1) * Bs], y_local[j * Bs:(j + 1) * Bs])
+            return out
+        return self._step(idx_local, y_local)
+
+    def _step(self, idx_local, y_local):
         B = idx_local.shape[0]
         inv_b = 1.0 / (B * self.world)
         idx_g = self._gathered("idx", idx_local)              # independent of the weights: issued first
+        if hasattr(self.backend, "start_sort"):
+            self.backend.start_sort(idx_g)
         S, dz, loss_b = self.backend.forward(idx_local, y_local, inv_b)
         S_g = self._gathered("S", S)
         dz_g = self._gathered("dz", dz)
