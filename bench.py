@@ -232,6 +232,8 @@ def main():
             for s in range(n):
                 j = (first + s) % N_POOL
                 out = dp.step(idx_pool[j], y_pool[j])
+                if s + 1 < n:
+                    dp.prefetch(idx_pool[(first + s + 1) % N_POOL])   # next step's index gather + sort, off its critical path
             return out
         work = torch.cuda.Stream(device=dev)          # not the legacy default stream (slow to enqueue on)
         with torch.cuda.stream(work):

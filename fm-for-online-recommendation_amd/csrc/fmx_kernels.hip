@@ -347,6 +347,7 @@ struct FwdArgs {
   fmx_fwd_out_t out;
   fmx_hyper_t h;
   int32_t B, F, kp, stride, zoff, loss_kind;
+  int32_t ldS, ld1;  // floats between consecutive samples in out.S and in out.dz / out.loss (kp and 1 when dense)
   float inv_b;
 };
 
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
   fo = __shfl(fo, 0);
 
   if (lane < LPR) {
-    if (a.out.S) *reinterpret_cast<float4 *>(a.out.S + (size_t)b * kp + 4 * q) = s;
+    if (a.out.S) *reinterpret_cast<float4 *>(a.out.S + (size_t)b * a.ldS + 4 * q) = s;
     if (a.out.bi) *reinterpret_cast<float4 *>(a.out.bi + (size_t)b * kp + 4 * q) = bi;
   }
   if (lane == 0) {
@@ -459,8 +460,8 @@ __global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
         loss = bcewl(p, y);
         dz = (sigmoidf_(p) - y) * p * (1.f - p) * a.inv_b;
       }
-      if (a.out.loss) a.out.loss[b] = loss;
-      if (a.out.dz) a.out.dz[b] = dz;
+      if (a.out.loss) a.out.loss[(size_t)b * a.ld1] = loss;
+      if (a.out.dz) a.out.dz[(size_t)b * a.ld1] = dz;
     }
   }
 }
@@ -485,6 +486,7 @@ struct UpdArgs {
   int32_t *step_counter;  // null: loss_out[0]; else loss_out[*step_counter], then *step_counter += 1
   fmx_hyper_t h;
   int32_t B, F, Bp, bbits, kp, stride, zoff;
+  int32_t ldS, ld1;  // floats between consecutive samples in S and in dz_first / dz_bi / loss_b (kp and 1 when dense)
   float inv_b;
 };
 
@@ -493,16 +495,21 @@ constexpr int LEAD_NONE = 0, LEAD_CLOSES = 1, LEAD_THROUGH = 2;
 
 // deterministic block reduction of src[0..n): every thread sums a strided set of 16-byte groups (all loads of a thread
 // are independent and issued together), then an LDS tree.  The order depends only on (n, blockDim).
-__device__ float block_sum(const float *src, int n, float *sm) {
+__device__ float block_sum(const float *src, int n, int ld, float *sm) {
   float acc = 0.f;
-  const int n4 = n >> 2;
-  const float4 *src4 = reinterpret_cast<const float4 *>(src);
+  if (ld == 1) {
+    const int n4 = n >> 2;
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
 #pragma unroll 4
-  for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-    const float4 v = src4[i];
-    acc += (v.x + v.y) + (v.z + v.w);
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      const float4 v = src4[i];
+      acc += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += src[i];
+  } else {  // strided sample records: same order of additions per thread as the dense form would give for n4 = 0
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += src[(size_t)i * ld];
   }
-  for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += src[i];
   sm[threadIdx.x] = acc;
   __syncthreads();
   for (int w = blockDim.x >> 1; w > 0; w >>= 1) {
@@ -517,9 +524,9 @@ __device__ float block_sum(const float *src, int n, float *sm) {
 template <int LAYOUT, int RULE>
 __device__ void bias_and_loss(const UpdArgs &a) {
   __shared__ float sm[256];
-  const float db = block_sum(a.dz_first, a.B, sm);
+  const float db = block_sum(a.dz_first, a.B, a.ld1, sm);
   float ls = 0.f;
-  if (a.loss_b && a.loss_out) ls = block_sum(a.loss_b, a.B, sm);
+  if (a.loss_b && a.loss_out) ls = block_sum(a.loss_b, a.B, a.ld1, sm);
   if (threadIdx.x == 0) {
     if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
       a.bias[0] = apply_rule<RULE>(a.bias[0], db, a.h);
@@ -699,10 +706,10 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
     cw[j] = 0.f;
     if (val[j]) {
       const uint32_t b = c[j] & bmask;
-      const float4 S4 = *reinterpret_cast<const float4 *>(a.S + (size_t)b * kp + 4 * q);
+      const float4 S4 = *reinterpret_cast<const float4 *>(a.S + (size_t)b * a.ldS + 4 * q);
       const float x = a.xv ? a.xv[(size_t)b * a.F + f] : 1.f;
-      const float dzf = a.dz_first[b];
-      const float dzb = a.dz_bi == a.dz_first ? dzf : (a.dz_bi ? a.dz_bi[b] : 0.f);
+      const float dzf = a.dz_first[(size_t)b * a.ld1];
+      const float dzb = a.dz_bi == a.dz_first ? dzf : (a.dz_bi ? a.dz_bi[(size_t)b * a.ld1] : 0.f);
       cw[j] = x * dzf;
       if constexpr (HAS_GBI) {
         const float4 G = splat(dzb) + *reinterpret_cast<const float4 *>(a.gbi + (size_t)b * kp + 4 * q);
@@ -1365,6 +1372,8 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
 int forward_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *xv, const float *y,
                  int32_t B, int32_t loss_kind, float inv_b, const fmx_fwd_out_t *out, hipStream_t st) {
   FwdArgs a;
+  a.ldS = out->sample_ld > 0 ? out->sample_ld : table->kp;
+  a.ld1 = out->sample_ld > 0 ? out->sample_ld : 1;
   a.rows = table->rows;
   a.foff = table->field_offsets;
   a.bias = table->bias;
@@ -1395,8 +1404,10 @@ int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
                 const uint32_t *sorted, const float *xv,
                 const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
                 const float *loss_b, float inv_b, float *loss_out, hipStream_t st, hipEvent_t mid,
-                int32_t *step_counter = nullptr, hipEvent_t stop = nullptr) {
+                int32_t *step_counter = nullptr, hipEvent_t stop = nullptr, int32_t sample_ld = 0) {
   UpdArgs a;
+  a.ldS = sample_ld > 0 ? sample_ld : table->kp;
+  a.ld1 = sample_ld > 0 ? sample_ld : 1;
   a.rows = table->rows;
   a.foff = table->field_offsets;
   a.bias = table->bias;
@@ -1440,6 +1451,8 @@ int check_forward_args(const fmx_table_t *table, const fmx_hyper_t *hyper, const
   if (loss_kind != FMX_LOSS_NONE && !y) return fail(FMX_ERR_ARG, "a loss needs labels y");
   if ((out->S && !aligned16(out->S)) || (out->bi && !aligned16(out->bi)))
     return fail(FMX_ERR_ALIGN, "S and bi must be 16-byte aligned");
+  if (out->sample_ld != 0 && (out->sample_ld < table->kp || out->sample_ld % 4))
+    return fail(FMX_ERR_SHAPE, "sample_ld=%d must be 0 or a multiple of 4 that is >= kp", out->sample_ld);
   return FMX_OK;
 }
 
@@ -1504,17 +1517,20 @@ int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B
 
 int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, void *workspace, const float *xv,
                   const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
-                  const float *loss_b, float inv_b, float *loss_out, fmx_stream_t stream) {
+                  int32_t sample_ld, const float *loss_b, float inv_b, float *loss_out, fmx_stream_t stream) {
   if (int rc = check_table(table)) return rc;
+  if (sample_ld != 0 && (sample_ld < table->kp || sample_ld % 4))
+    return fail(FMX_ERR_SHAPE, "sample_ld=%d must be 0 or a multiple of 4 that is >= kp", sample_ld);
   if (int rc = check_rule(table, rule)) return rc;
   if (!hyper || !workspace || !S || !dz_first) return fail(FMX_ERR_ARG, "fmx_fm_update: null argument");
   if (!dz_bi && !gbi) return fail(FMX_ERR_ARG, "fmx_fm_update: one of dz_bi / gbi is required");
   if (int rc = check_sort_geometry(table, B)) return rc;
-  if (!aligned16(workspace) || !aligned16(S) || (gbi && !aligned16(gbi)) || !aligned16(dz_first) || (loss_b && !aligned16(loss_b)))
-    return fail(FMX_ERR_ALIGN, "workspace, S, gbi, dz_first and loss_b must be 16-byte aligned");
+  if (!aligned16(workspace) || !aligned16(S) || (gbi && !aligned16(gbi)) ||
+      (sample_ld == 0 && (!aligned16(dz_first) || (loss_b && !aligned16(loss_b)))))
+    return fail(FMX_ERR_ALIGN, "workspace, S, gbi (and dense dz_first / loss_b) must be 16-byte aligned");
   const Workspace w = carve(table, B, workspace);
   return update_impl(table, hyper, rule, w, w.sorted, xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out,
-                     static_cast<hipStream_t>(stream), nullptr);
+                     static_cast<hipStream_t>(stream), nullptr, nullptr, nullptr, sample_ld);
 }
 
 int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,

@@ -42,7 +42,8 @@ class Mlp(C.Structure):
 
 
 class FwdOut(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("S", "bi", "first", "sfirst", "sbi", "logit", "loss", "dz", "error")]
+    _fields_ = ([(n, C.c_void_p) for n in ("S", "bi", "first", "sfirst", "sbi", "logit", "loss", "dz", "error")]
+                + [("sample_ld", C.c_int32), ("reserved", C.c_int32)])
 
 
 _lib = None
@@ -66,7 +67,7 @@ def load():
     lib.fmx_workspace_bytes.argtypes = [TP, i32]
     lib.fmx_fm_forward.argtypes = [TP, HP, p, p, p, i32, i32, f32, FP, p]
     lib.fmx_sort_occurrences.argtypes = [TP, p, i32, p, p, p]
-    lib.fmx_fm_update.argtypes = [TP, HP, i32, p, p, p, p, p, p, i32, p, f32, p, p]
+    lib.fmx_fm_update.argtypes = [TP, HP, i32, p, p, p, p, p, p, i32, i32, p, f32, p, p]
     lib.fmx_fm_step.argtypes = [TP, HP, i32, i32, p, p, p, i32, f32, p, FP, p, p]
     lib.fmx_fm_stream.argtypes = [TP, HP, i32, i32, p, p, i32, i32, f32, i32, p, FP, p, C.POINTER(C.c_float), p]
     lib.fmx_stream_read.argtypes = [p, i64, p, p]

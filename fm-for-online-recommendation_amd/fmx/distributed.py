@@ -3,7 +3,7 @@
 Exact by construction: every rank keeps a full replica of the table, runs the forward pass on its own slice of the
 global mini-batch, and the ranks all-gather what the backward needs.  For FM that is NOT the row gradients
 (39 x 68 B per sample) but their low-rank factors: the sample's indices, its sum vector S_b and its dlogit --
-(156 + 64 + 8) B per sample -- because every row gradient of a sample is  x (S_b - x V_row) dz_b.  Each rank then
+156 B of indices + one 80-byte record (S, dlogit, loss) per sample, two collectives per step -- because every row gradient of a sample is  x (S_b - x V_row) dz_b.  Each rank then
 runs the same deterministic sort + row-reduced update over the GLOBAL batch, so the replicas stay bit-identical,
 no embedding row ever crosses xGMI, and the G-GPU step equals the 1-GPU step on the same global batch
 (SURVEY.md section 8(e)).  The bias gradient is the sum of the gathered dlogits, so pure FM needs no all-reduce; a
@@ -34,9 +34,14 @@ class HipBackend:
         self.max_global_batch = max_step_batch(max(engine.table.feature_sizes))
 
     def forward(self, idx, y, inv_b):
-        """-> (S [B,kp], dz [B], loss_b [B]) views valid until the next forward."""
-        B = self.e.forward(self.hyper, idx, None, y, loss=self.loss, inv_b=inv_b, want_first=False, want_bi=False)
-        return self.e.S[:B], self.e.dz[:B], self.e.loss_b[:B]
+        """-> records [B, kp + 4]: per sample (S[kp], dz, loss, pad) -- one buffer, so ONE all-gather carries everything
+        the global update needs from this rank."""
+        B = idx.shape[0]
+        if getattr(self, "_rec", None) is None or self._rec.shape[0] < B:
+            self._rec = torch.zeros((B, self.e.table.kp + 4), dtype=torch.float32, device=self.e.device)
+        rec = self._rec[:B]
+        self.e.forward(self.hyper, idx, None, y, loss=self.loss, inv_b=inv_b, want_first=False, want_bi=False, records=rec)
+        return rec
 
     def start_sort(self, idx_g):
         """The global occurrence sort only needs the gathered indices: it runs on a side stream while this rank's
@@ -51,7 +56,7 @@ class HipBackend:
             e.sort(idx_g)
         self._sorted_for = idx_g.data_ptr()
 
-    def update(self, idx_g, S_g, dz_g, loss_g, inv_b):
+    def update(self, idx_g, rec_g, inv_b):
         """Row-reduced update over the global batch (sorted by start_sort, or here); returns the mean-loss tensor [1]."""
         e = self.e
         GB = idx_g.shape[0]
@@ -61,7 +66,7 @@ class HipBackend:
         else:
             e.sort(idx_g)
         self._sorted_for = None
-        e.update(self.hyper, self.rule, GB, None, dz_g, dz_g, None, inv_b=inv_b, with_loss=True, S=S_g, loss_b=loss_g)
+        e.update(self.hyper, self.rule, GB, None, None, inv_b=inv_b, with_loss=True, records=rec_g)
         return e.loss_out
 
 
@@ -111,14 +116,27 @@ class DataParallelFM:
             return out
         return self._step(idx_local, y_local)
 
+    def prefetch(self, idx_next):
+        """Gather (and start sorting) the NEXT step's indices now: they do not depend on the weights, and it takes the
+        index all-gather off the next step's critical path.  Two alternating buffers, so a prefetch issued while a step
+        still reads its own gathered indices does not overwrite them."""
+        self._pf_toggle = 1 - getattr(self, "_pf_toggle", 0)
+        idx_g = self._gathered(f"idx_pf{self._pf_toggle}", idx_next)
+        self._pref = (idx_next.data_ptr(), idx_g)
+        cap = getattr(self.backend, "max_global_batch", None)
+        if hasattr(self.backend, "start_sort") and (cap is None or idx_g.shape[0] <= cap):
+            self.backend.start_sort(idx_g)
+
     def _step(self, idx_local, y_local):
         B = idx_local.shape[0]
         inv_b = 1.0 / (B * self.world)
-        idx_g = self._gathered("idx", idx_local)              # independent of the weights: issued first
-        if hasattr(self.backend, "start_sort"):
-            self.backend.start_sort(idx_g)
-        S, dz, loss_b = self.backend.forward(idx_local, y_local, inv_b)
-        S_g = self._gathered("S", S)
-        dz_g = self._gathered("dz", dz)
-        loss_g = self._gathered("loss", loss_b)
-        return self.backend.update(idx_g, S_g, dz_g, loss_g, inv_b)
+        pref, self._pref = getattr(self, "_pref", None), None
+        if pref is not None and pref[0] == idx_local.data_ptr() and pref[1].shape[0] == B * self.world:
+            idx_g = pref[1]                                   # gathered (and being sorted) since the previous step
+        else:
+            idx_g = self._gathered("idx", idx_local)          # independent of the weights: issued first
+            if hasattr(self.backend, "start_sort"):
+                self.backend.start_sort(idx_g)
+        rec = self.backend.forward(idx_local, y_local, inv_b)
+        rec_g = self._gathered("rec", rec)
+        return self.backend.update(idx_g, rec_g, inv_b)

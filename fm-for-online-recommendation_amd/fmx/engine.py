@@ -95,10 +95,17 @@ class FMEngine:
         return idx_d, xv_d, y_d
 
     # ---- kernels ----
-    def forward(self, hyper, idx_d, xv_d=None, y_d=None, loss=None, inv_b=None, want_first=True, want_bi=True):
+    def forward(self, hyper, idx_d, xv_d=None, y_d=None, loss=None, inv_b=None, want_first=True, want_bi=True, records=None):
+        """records: optional [B, ld] fp32 tensor (ld >= kp + 2, multiple of 4): S, dz and loss are written as fields of one
+        per-sample record (S = rec[:kp], dz = rec[kp], loss = rec[kp + 1]) instead of the engine's dense buffers."""
         B = idx_d.shape[0]
         self._ensure(B)
         out = self._fwd_out(want_first, want_bi)
+        if records is not None:
+            kp, ld = self.table.kp, records.shape[1]
+            assert records.shape[0] >= B and ld >= kp + 2 and ld % 4 == 0 and records.is_contiguous()
+            base = records.data_ptr()
+            out.S, out.dz, out.loss, out.sample_ld = base, base + 4 * kp, base + 4 * (kp + 1), ld
         inv_b = 1.0 / B if inv_b is None else inv_b
         _lib.check(self.lib.fmx_fm_forward(self.table.c_struct(), hyper.ref(), idx_d.data_ptr(), _ptr(xv_d), _ptr(y_d), B,
                                            _lib.LOSSES[loss], inv_b, C.byref(out), self._stream()))
@@ -110,15 +117,25 @@ class FMEngine:
         _lib.check(self.lib.fmx_sort_occurrences(self.table.c_struct(), idx_d.data_ptr(), B, self.workspace.data_ptr(),
                                                  self.error.data_ptr(), self._stream()))
 
-    def update(self, hyper, rule, B, xv_d, dz_first, dz_bi=None, gbi=None, inv_b=None, with_loss=True, S=None, loss_b=None):
+    def update(self, hyper, rule, B, xv_d, dz_first, dz_bi=None, gbi=None, inv_b=None, with_loss=True, S=None, loss_b=None,
+               records=None, fm_term=True):
         """Row-reduced backward + fused update for the batch whose occurrences self.sort() just listed.
-        S / loss_b default to the buffers the last forward() filled (a data-parallel caller passes gathered ones)."""
+        S / loss_b default to the buffers the last forward() filled (a data-parallel caller passes gathered ones, or
+        `records` [B, ld] as written by forward(records=...): then dz_first = dz_bi = the records' dz field)."""
         inv_b = 1.0 / B if inv_b is None else inv_b
-        S = self.S if S is None else S
-        loss_b = self.loss_b if loss_b is None else loss_b
+        ld = 0
+        if records is not None:
+            kp, ld = self.table.kp, records.shape[1]
+            base = records.data_ptr()
+            S_p, dzf_p, loss_p = base, base + 4 * kp, base + 4 * (kp + 1)
+            dzb_p = dzf_p if fm_term else None
+        else:
+            S = self.S if S is None else S
+            loss_b = self.loss_b if loss_b is None else loss_b
+            S_p, dzf_p, dzb_p, loss_p = S.data_ptr(), dz_first.data_ptr(), _ptr(dz_bi), loss_b.data_ptr()
         _lib.check(self.lib.fmx_fm_update(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], self.workspace.data_ptr(),
-                                          _ptr(xv_d), S.data_ptr(), dz_first.data_ptr(), _ptr(dz_bi), _ptr(gbi), B,
-                                          loss_b.data_ptr() if with_loss else None, inv_b,
+                                          _ptr(xv_d), S_p, dzf_p, dzb_p, _ptr(gbi), B, ld,
+                                          loss_p if with_loss else None, inv_b,
                                           self.loss_out.data_ptr() if with_loss else None, self._stream()))
 
     def step(self, hyper, rule, loss, idx_d, xv_d, y_d, inv_b=None):

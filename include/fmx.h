@@ -96,6 +96,10 @@ typedef struct fmx_fwd_out {
   float *loss;    /* [B]      per-sample loss (unscaled), needs y                                     */
   float *dz;      /* [B]      d(mean loss)/d logit = (...) * inv_b, needs y                           */
   int32_t *error; /* [1]      set to 1 when an index is outside its field (that row is treated as 0)  */
+  int32_t sample_ld; /* 0: S, loss, dz are dense arrays as above.  > 0 (multiple of 4, >= kp): element b of S, of loss and
+                        of dz lies sample_ld floats after element b-1 -- the three pointers then address fields of one
+                        per-sample record, which a data-parallel caller all-gathers with ONE collective */
+  int32_t reserved;
 } fmx_fwd_out_t;
 
 int fmx_version(void);
@@ -150,10 +154,11 @@ int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B
  *   dz_bi     [B] or null: scalar coefficient on every bi component (the FM term sum_d bi_d)
  *   gbi       [B, kp] or null: dL/dbi from a network on top of bi (DeepFM / NFM)
  *   loss_b    [B] or null with loss_out [1] or null: loss_out = inv_b * sum_b loss_b (deterministic order)
+ *   sample_ld 0, or the record stride of fmx_fwd_out_t.sample_ld: applies to S, dz_first, dz_bi and loss_b (gbi is dense)
  */
 int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, void *workspace,
                   const float *xv, const float *S, const float *dz_first, const float *dz_bi, const float *gbi,
-                  int32_t B, const float *loss_b, float inv_b, float *loss_out, fmx_stream_t stream);
+                  int32_t B, int32_t sample_ld, const float *loss_b, float inv_b, float *loss_out, fmx_stream_t stream);
 
 /* One pure-FM mini-batch step = sort + forward(+loss) + update on one stream.
  * Replaces: FMAdam.update_embedding / FMAdam.fit (reference fm_adam.py:56-82) and every class's

@@ -31,20 +31,24 @@ class OracleBackend:
         rows = idx.numpy().astype(np.int64) + self.offs[None, :]
         fw = orc.flat_forward(V, w, b, rows, np.ones(rows.shape, dtype=np.float32))
         yv = y.numpy()
-        dz = orc.dloss_dlogit(fw["logit"], yv, "logits", inv_b)
-        return torch.from_numpy(fw["S"]), torch.from_numpy(dz), torch.from_numpy(orc.loss_value(fw["logit"], yv, "logits"))
+        rec = np.zeros((len(yv), K + 4), dtype=np.float32)      # the product's record: S | dz | loss | pad
+        rec[:, :K] = fw["S"]
+        rec[:, K] = orc.dloss_dlogit(fw["logit"], yv, "logits", inv_b)
+        rec[:, K + 1] = orc.loss_value(fw["logit"], yv, "logits")
+        return torch.from_numpy(rec)
 
-    def update(self, idx_g, S_g, dz_g, loss_g, inv_b):
+    def update(self, idx_g, rec_g, inv_b):
         st = self.st
         V = orc.ftrl_weight(st["zV"], st["nV"], **HYP)
         rows = idx_g.numpy().astype(np.int64) + self.offs[None, :]
-        S, dz = S_g.numpy(), dz_g.numpy()
+        rec = rec_g.numpy()
+        S, dz, loss_g = np.ascontiguousarray(rec[:, :K]), np.ascontiguousarray(rec[:, K]), rec[:, K + 1]
         x = np.ones(rows.shape, dtype=np.float32)
         u, dV, dw = orc.flat_row_gradients(V, rows, x, S, dz, np.repeat(dz[:, None], V.shape[1], axis=1))
         st["zV"][u], st["nV"][u] = orc.ftrl_step(st["zV"][u], st["nV"][u], dV, **HYP)
         st["zw"][u], st["nw"][u] = orc.ftrl_step(st["zw"][u], st["nw"][u], dw, **HYP)
         st["zb"], st["nb"] = orc.ftrl_step(st["zb"], st["nb"], dz.sum(dtype=np.float32), **HYP)
-        return torch.tensor([float(loss_g.numpy().sum(dtype=np.float32) * np.float32(inv_b))])
+        return torch.tensor([float(loss_g.sum(dtype=np.float32) * np.float32(inv_b))])
 
 
 def make_state():
@@ -76,9 +80,12 @@ def _worker(rank, world, port, q):
     st, offs = make_state()
     dp = fmx.DataParallelFM(OracleBackend(st, offs))
     losses = []
-    for idx, y in make_batches(world):
-        sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL)
-        losses.append(float(dp.step(torch.from_numpy(idx[sl]), torch.from_numpy(y[sl]))[0]))
+    sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL)
+    batches = [(torch.from_numpy(idx[sl].copy()), torch.from_numpy(y[sl].copy())) for idx, y in make_batches(world)]
+    for i, (idx_t, y_t) in enumerate(batches):
+        losses.append(float(dp.step(idx_t, y_t)[0]))
+        if i + 1 < len(batches) and i % 2 == 0:
+            dp.prefetch(batches[i + 1][0])              # every other step takes the prefetched-index path
     q.put((rank, losses, {k: np.asarray(v).copy() for k, v in st.items()}))
     dist.barrier()
     dist.destroy_process_group()
