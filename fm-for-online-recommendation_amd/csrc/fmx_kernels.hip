@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 
 #include "fmx.h"
@@ -487,6 +488,8 @@ struct UpdArgs {
   fmx_hyper_t h;
   int32_t B, F, Bp, bbits, kp, stride, zoff;
   int32_t ldS, ld1;  // floats between consecutive samples in S and in dz_first / dz_bi / loss_b (kp and 1 when dense)
+  uint32_t seq;      // INL: launch sequence number tagging the tile meta words of this launch
+  int32_t *error;    // INL: set to 2 if a hand-off wait ran into its bound
   float inv_b;
 };
 
@@ -601,6 +604,26 @@ __device__ __forceinline__ void update_row(float *rp, int q, int kp, int zoff, R
   }
 }
 
+// Agent-scope relaxed atomic accesses compile to `global_store/load ... sc1` (write-through / L1-bypassing): the form
+// the in-launch hand-off of partial records uses on BOTH sides (MI355X_MICROARCH.md, "Valid forms": every store and every
+// load of the handed-off bytes sc1, the storing wave's s_waitcnt vmcnt(0) before its flag store).
+__device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ld_sc1_4(const float *p) { return {ld_sc1(p), ld_sc1(p + 1), ld_sc1(p + 2), ld_sc1(p + 3)}; }
+__device__ __forceinline__ void store_part_sc1(float *rec, int q, int kp, float4 cV, float4 cA, float cw) {
+  st_sc1(rec + 4 * q, cV.x);
+  st_sc1(rec + 4 * q + 1, cV.y);
+  st_sc1(rec + 4 * q + 2, cV.z);
+  st_sc1(rec + 4 * q + 3, cV.w);
+  st_sc1(rec + kp + 4 * q, cA.x);
+  st_sc1(rec + kp + 4 * q + 1, cA.y);
+  st_sc1(rec + kp + 4 * q + 2, cA.z);
+  st_sc1(rec + kp + 4 * q + 3, cA.w);
+  if (q == 0) st_sc1(rec + 2 * kp, cw);
+}
+
 // partial-sum record: [cV (kp) | cA (kp) | cw, pad3]
 __device__ __forceinline__ void store_part(float *rec, int q, int kp, float4 cV, float4 cA, float cw) {
   *reinterpret_cast<float4 *>(rec + 4 * q) = cV;
@@ -629,7 +652,7 @@ template <> struct CoefA<false> {
 // walks EPG = 64 / SLOTS CONSECUTIVE occurrences sequentially, so duplicates inside a group are summed in registers;
 // one segmented scan over the SLOTS groups (log2(SLOTS) steps of wave shuffles) carries the sums of runs that span
 // groups.  At the tail of a run: the row update when the run began in this tile, a partial record otherwise.
-template <int LPR, int LAYOUT, int RULE, bool HAS_GBI>
+template <int LPR, int LAYOUT, int RULE, bool HAS_GBI, bool INL>
 __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   constexpr int SLOTS = WAVE / LPR;  // lane groups
   constexpr int EPG = LPR;           // consecutive occurrences per group
@@ -794,7 +817,9 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
         const RowRegs r = PREFETCH_ROWS ? row[PREFETCH_ROWS ? j : 0] : load_row<LAYOUT>(rp, q, kp, a.zoff);
         update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, accV, accA.vec(), accw, a.h);
       } else {
-        store_part(part, q, kp, accV, accA.vec(), accw);  // the run that came in from the previous tile ends here
+        // the run that came in from the previous tile ends here
+        if (INL) store_part_sc1(part, q, kp, accV, accA.vec(), accw);
+        else store_part(part, q, kp, accV, accA.vec(), accw);
         closes = true;
       }
     }
@@ -807,12 +832,81 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
     const bool through = __shfl((int)(k[EPG - 1] == tile_prevkey), WAVE - 1) != 0;
     if (through) lead_state = LEAD_THROUGH;  // the whole tile is one run, open at both ends
     else trail_state = 1;
-    if (slot == SLOTS - 1) store_part(part + (through ? 0 : REC), q, kp, tV, tA.vec(), tw);
+    if (slot == SLOTS - 1) {
+      if (INL) store_part_sc1(part + (through ? 0 : REC), q, kp, tV, tA.vec(), tw);
+      else store_part(part + (through ? 0 : REC), q, kp, tV, tA.vec(), tw);
+    }
   }
-  if (lane == 0) {
-    a.meta[(size_t)gt * 2] = lead_state;
-    a.meta[(size_t)gt * 2 + 1] = trail_state;
+  if (!INL) {
+    if (lane == 0) {
+      a.meta[(size_t)gt * 2] = lead_state;
+      a.meta[(size_t)gt * 2 + 1] = trail_state;
+    }
+    return;
   }
+  // ---- in-launch hand-off (INL): publish this tile's records, then the CLOSING tile of a run sums the records of the
+  //      tiles before it (they were dispatched earlier and wait on nothing) and applies the row update -- no second
+  //      launch.  Flag word = (launch sequence << 4) | lead_state << 2 | trail_state, stored after the records are
+  //      acknowledged (vmcnt(0)); records and flags are sc1 on both sides. ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0)
+    __hip_atomic_store(a.meta + (size_t)gt * 2, (int32_t)((a.seq << 4) | ((uint32_t)lead_state << 2) | (uint32_t)trail_state),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lead_state != LEAD_CLOSES) return;  // wave-uniform
+  const int t = gt - f * tiles_per_field;
+  float *rp = a.rows + (row0 + tile_prevkey) * (size_t)a.stride;
+  RowRegs r;
+  if (lane < LPR) r = load_row<LAYOUT>(rp, q, kp, a.zoff);  // the row is final until this wave writes it
+  // distance m to the head tile: tiles t-1, t-2, ... are THROUGH until the head (trail_state == 1)
+  int m = 0;
+  bool failed = false;
+  for (int j0 = 1; j0 <= t && m == 0 && !failed; j0 += 64) {
+    const int tj = t - j0 - lane;  // lane i looks at tile t - j0 - i
+    int w = 0;
+    bool ready = false;
+    for (int spin = 0;; ++spin) {
+      if (tj >= 0 && !ready) {
+        w = __hip_atomic_load(a.meta + ((size_t)f * tiles_per_field + tj) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ready = ((uint32_t)w >> 4) == (a.seq & 0x0FFFFFFFu);
+      }
+      const bool is_through = tj >= 0 && ready && ((w >> 2) & 3) == LEAD_THROUGH;
+      const unsigned long long stop = __ballot(!is_through);  // not published yet, or not THROUGH, or before the field
+      if (stop == 0ull) break;                                // 64 THROUGH tiles: look further back
+      const int pos = __ffsll((long long)stop) - 1;
+      const bool resolved = __shfl((int)(ready || tj < 0), pos) != 0;
+      if (resolved) {  // the chain ends at a published tile: it must be the head (its last run goes on)
+        if (__shfl((int)(tj >= 0 && (w & 3) == 1), pos) != 0) m = j0 + pos;
+        else failed = true;
+        break;
+      }
+      if (spin >= (1 << 20)) {
+        failed = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  if (failed || m == 0 || m > t) {
+    if (lane == 0 && a.error) *a.error = 2;
+    return;
+  }
+  // the same record order and lane-group assignment as k_fm_fixup, so both modes give identical bits
+  const size_t gh = (size_t)gt - m;
+  float4 aV = splat(0.f), aA = splat(0.f);
+  float aw = 0.f;
+  for (int j = slot; j <= m; j += SLOTS) {
+    const float *rec = j == 0 ? a.parts + (gh * 2 + 1) * REC : a.parts + (gh + j) * 2 * REC;
+    aV = aV + ld_sc1_4(rec + 4 * q);
+    aA = aA + ld_sc1_4(rec + kp + 4 * q);
+    aw += ld_sc1(rec + 2 * kp);
+  }
+#pragma unroll
+  for (int mm = LPR; mm < WAVE; mm <<= 1) {
+    aV = aV + shfl_xor4(aV, mm);
+    aA = aA + shfl_xor4(aA, mm);
+    aw += __shfl_xor(aw, mm);
+  }
+  if (lane < LPR) update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, aV, aA, aw, a.h);
 }
 
 // Runs that cross tile boundaries: the wave of the tile holding the run's head adds the partial sums in tile order
@@ -1120,14 +1214,16 @@ struct Tune {
   int sort_e = 0;     // FMX_SORT_E: elements per thread of the bitonic sort (0 = default)
   int ext_events = 0; // FMX_EXT_EVENTS=1: completion events ride on the launches (hipExtLaunchKernel); slower on the host
   int sort_debug = 0;
+  int inline_fixup = 1;  // FMX_INLINE_FIXUP=0 / fmx_set_option("inline_fixup", 0): partial records are combined by a second
+                         // launch (k_fm_fixup) instead of the in-launch hand-off; both give identical bits
   int stream_prio = 1;  // FMX_STREAM_PRIO=0: no stream priorities
   int sort_ahead = 8;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..8)
   int sort_merge = 0; // FMX_SORT_MERGE=1: in-wave sort + binary-search merge rounds in LDS (measured slower: 31 vs 22 us,
                       // the merge rounds are LDS-bandwidth bound)
   int sort_cus = 0;   // FMX_SORT_CUS=n: reserve n CUs for the side-stream sort (CU-masked library streams)
 };
-const Tune &tune() {
-  static const Tune t = [] {
+Tune &tune() {
+  static Tune t = [] {
     Tune x;
     if (const char *e = getenv("FMX_WPB_FWD")) x.wpb_fwd = atoi(e);
     if (const char *e = getenv("FMX_WPB_UPD")) x.wpb_upd = atoi(e);
@@ -1137,6 +1233,7 @@ const Tune &tune() {
     if (const char *e = getenv("FMX_SORT_MERGE")) x.sort_merge = atoi(e);
     if (const char *e = getenv("FMX_SORT_DEBUG")) x.sort_debug = atoi(e);
     if (const char *e = getenv("FMX_SORT_AHEAD")) x.sort_ahead = atoi(e);
+    if (const char *e = getenv("FMX_INLINE_FIXUP")) x.inline_fixup = atoi(e);
     if (const char *e = getenv("FMX_STREAM_PRIO")) x.stream_prio = atoi(e);
     auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
     if (!ok(x.wpb_fwd)) x.wpb_fwd = 4;
@@ -1255,20 +1352,20 @@ void launch_forward(const FwdArgs &a, int layout, hipStream_t st) {
   }
 }
 
-template <int LPR, bool HAS_GBI>
+template <int LPR, bool HAS_GBI, bool INL>
 void launch_update(const UpdArgs &a, int rule, hipStream_t st) {
   const int tiles = a.F * (a.Bp >> 6);
   const int wpb = tune().wpb_upd;
   const dim3 grid((tiles + wpb - 1) / wpb + 1), block(64 * wpb);
   switch (rule) {
     case FMX_RULE_SIGNADAM:
-      hipLaunchKernelGGL((k_fm_update<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, HAS_GBI>), grid, block, 0, st, a);
+      hipLaunchKernelGGL((k_fm_update<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, HAS_GBI, INL>), grid, block, 0, st, a);
       break;
     case FMX_RULE_SGD:
-      hipLaunchKernelGGL((k_fm_update<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, HAS_GBI>), grid, block, 0, st, a);
+      hipLaunchKernelGGL((k_fm_update<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, HAS_GBI, INL>), grid, block, 0, st, a);
       break;
     default:
-      hipLaunchKernelGGL((k_fm_update<LPR, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, HAS_GBI>), grid, block, 0, st, a);
+      hipLaunchKernelGGL((k_fm_update<LPR, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, HAS_GBI, INL>), grid, block, 0, st, a);
       break;
   }
 }
@@ -1293,8 +1390,15 @@ void launch_fixup(const UpdArgs &a, int rule, hipStream_t st, hipEvent_t stop) {
 
 template <int LPR>
 void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st, hipEvent_t mid, hipEvent_t stop) {
-  if (has_gbi) launch_update<LPR, true>(a, rule, st);
-  else launch_update<LPR, false>(a, rule, st);
+  if (tune().inline_fixup) {  // one launch: the closing tile of a run that crosses tiles sums the partial records itself
+    if (has_gbi) launch_update<LPR, true, true>(a, rule, st);
+    else launch_update<LPR, false, true>(a, rule, st);
+    if (mid) (void)hipEventRecord(mid, st);
+    if (stop) (void)hipEventRecord(stop, st);
+    return;
+  }
+  if (has_gbi) launch_update<LPR, true, false>(a, rule, st);
+  else launch_update<LPR, false, false>(a, rule, st);
   if (mid) (void)hipEventRecord(mid, st);
   launch_fixup<LPR>(a, rule, st, stop);
 }
@@ -1404,10 +1508,15 @@ int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
                 const uint32_t *sorted, const float *xv,
                 const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
                 const float *loss_b, float inv_b, float *loss_out, hipStream_t st, hipEvent_t mid,
-                int32_t *step_counter = nullptr, hipEvent_t stop = nullptr, int32_t sample_ld = 0) {
+                int32_t *step_counter = nullptr, hipEvent_t stop = nullptr, int32_t sample_ld = 0,
+                int32_t *err_flag = nullptr) {
   UpdArgs a;
   a.ldS = sample_ld > 0 ? sample_ld : table->kp;
   a.ld1 = sample_ld > 0 ? sample_ld : 1;
+  static std::atomic<uint32_t> launch_seq{1};
+  a.seq = launch_seq.fetch_add(1) & 0x0FFFFFFFu;
+  if (a.seq == 0) a.seq = launch_seq.fetch_add(1) & 0x0FFFFFFFu;  // 0 is what a zeroed workspace holds
+  a.error = err_flag;
   a.rows = table->rows;
   a.foff = table->field_offsets;
   a.bias = table->bias;
@@ -1478,6 +1587,18 @@ int check_step_args(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t 
 extern "C" {
 
 int fmx_version(void) { return FMX_VERSION; }
+
+int fmx_set_option(const char *name, int value) {
+  if (!name) return fail(FMX_ERR_ARG, "fmx_set_option: null name");
+  Tune &t = tune();
+  int *slot = nullptr;
+  if (!strcmp(name, "inline_fixup")) slot = &t.inline_fixup;
+  else if (!strcmp(name, "sort_ahead")) slot = &t.sort_ahead;
+  else return fail(FMX_ERR_ARG, "fmx_set_option: unknown option '%s'", name);
+  const int old = *slot;
+  *slot = value;
+  return old;
+}
 
 const char *fmx_last_error_string(void) { return g_err; }
 
@@ -1553,7 +1674,7 @@ int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
     if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
   }
   return update_impl(table, hyper, rule, w, w.sorted, xv, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b, loss_out, st,
-                     nullptr);
+                     nullptr, nullptr, nullptr, 0, fwd->error);
 }
 
 int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
@@ -1629,7 +1750,7 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
         if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
         if (rc == FMX_OK)
           rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                           loss_out, st, nullptr, loss_out ? w.counter : nullptr);
+                           loss_out, st, nullptr, loss_out ? w.counter : nullptr, nullptr, 0, fwd->error);
       }
       if (sd) (void)hipEventRecord(sd->consumed[g & 1], st);
     }

@@ -14,7 +14,7 @@ LOSS_NONE, LOSS_BCE_LOGITS, LOSS_BCE_SIGMOID = 0, 1, 2
 RULES = {"signadam": RULE_SIGNADAM, "sgd": RULE_SGD, "ftrl": RULE_FTRL}
 LOSSES = {None: LOSS_NONE, "none": LOSS_NONE, "logits": LOSS_BCE_LOGITS, "sigmoid": LOSS_BCE_SIGMOID}
 
-EXPORTS = ["fmx_version", "fmx_last_error_string", "fmx_sorted_width", "fmx_sorted_bbits", "fmx_workspace_bytes",
+EXPORTS = ["fmx_version", "fmx_last_error_string", "fmx_set_option", "fmx_sorted_width", "fmx_sorted_bbits", "fmx_workspace_bytes",
            "fmx_fm_forward", "fmx_mlp_forward", "fmx_mlp_fit", "fmx_mlp_hedge_fit",
            "fmx_sort_occurrences", "fmx_fm_update", "fmx_fm_step", "fmx_fm_stream", "fmx_stream_read"]
 
@@ -62,6 +62,7 @@ def load():
     TP, HP, FP = C.POINTER(Table), C.POINTER(Hyper), C.POINTER(FwdOut)
     lib.fmx_version.restype = C.c_int
     lib.fmx_last_error_string.restype = C.c_char_p
+    lib.fmx_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.fmx_sorted_width.argtypes = [C.c_int]
     lib.fmx_sorted_bbits.argtypes = [C.c_int]
     lib.fmx_workspace_bytes.argtypes = [TP, i32]

@@ -105,6 +105,12 @@ typedef struct fmx_fwd_out {
 int fmx_version(void);
 const char *fmx_last_error_string(void);
 
+/* Process-wide tuning switches; returns the previous value (>= 0) or a negative status for an unknown name.
+ *   "inline_fixup" (default 1)  1: runs that cross 64-occurrence tiles are finished inside k_fm_update by an in-launch
+ *                                hand-off; 0: by a second launch (k_fm_fixup).  Both orders of summation are the same: identical bits.
+ *   "sort_ahead"   (default 8)  batches sorted per side-stream launch in fmx_fm_stream (1..8). */
+int fmx_set_option(const char *name, int value);
+
 /* Smallest sort width for a batch: max(64, next power of two >= B); and log2 of it. */
 int fmx_sorted_width(int B);
 int fmx_sorted_bbits(int B);

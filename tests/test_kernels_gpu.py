@@ -463,3 +463,39 @@ def test_step_shape_sweep(fmx, F, k, B):
         # the cached weights equal the weights derived from the stored (z, n)
         Vc = t.rows[:, :k].cpu().numpy()
         np.testing.assert_allclose(Vc, orc.ftrl_weight(zV, nV, **h), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("zipf", [False, True])
+def test_inline_fixup_and_second_launch_give_identical_bits(fmx, zipf):
+    """Runs that cross tiles are finished either by an in-launch hand-off (default) or by k_fm_fixup: same record order,
+    so the tables must agree bit for bit over a few hundred full-size steps (and no hand-off wait may hit its bound)."""
+    sizes, k, B, n_pool, n_steps = CRITEO_SIZES, 16, 4096, 4, 200
+    rng = np.random.default_rng(11)
+    if zipf:
+        idx = np.stack([np.stack([np.minimum(rng.zipf(1.1, size=B) - 1, s - 1) for s in sizes], axis=1)
+                        for _ in range(n_pool)]).astype(np.int32)
+    else:
+        idx = np.stack([np.stack([rng.integers(0, s, size=B) for s in sizes], axis=1) for _ in range(n_pool)]).astype(np.int32)
+    y = (rng.uniform(size=(n_pool, B)) < 0.3).astype(np.float32)
+    idx_pool, y_pool = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
+    R = sum(sizes)
+    V0 = torch.from_numpy((rng.normal(size=(R, k)) * 0.05).astype(np.float32)).cuda()
+    res = []
+    lib = fmx._lib.load()
+    for mode in (1, 0):
+        prev = lib.fmx_set_option(b"inline_fixup", mode)
+        try:
+            t = fmx.FlatTable(sizes, k, layout="ftrl", ftrl=HYP)
+            t.rows[:, :k] = V0
+            t.rows[:, t.z_offset:t.z_offset + k] = fmx.table.ftrl_z_for_weight_torch(V0, t.ftrl)
+            eng = fmx.FMEngine(t, max_batch=B)
+            loss = torch.zeros(n_steps, device="cuda")
+            eng.stream(fmx.Hyper(**HYP), "ftrl", "logits", idx_pool, y_pool, n_steps, loss)
+            torch.cuda.synchronize()
+            eng.check_error_flag()
+            res.append((t.rows.cpu().numpy(), t.bias.cpu().numpy(), loss.cpu().numpy()))
+        finally:
+            lib.fmx_set_option(b"inline_fixup", prev)
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, b)
+    assert np.isfinite(res[0][2]).all()
