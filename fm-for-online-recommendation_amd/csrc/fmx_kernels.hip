@@ -338,6 +338,26 @@ __global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // k_fm_forward
 // ------------------------------------------------------------------------------------------------------------
+// Agent-scope relaxed atomic accesses compile to `global_store/load ... sc1` (write-through / L1-bypassing): the form
+// the in-launch hand-off of partial records uses on BOTH sides (MI355X_MICROARCH.md, "Valid forms": every store and every
+// load of the handed-off bytes sc1, the storing wave's s_waitcnt vmcnt(0) before its flag store).
+__device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ld_sc1_4(const float *p) { return {ld_sc1(p), ld_sc1(p + 1), ld_sc1(p + 2), ld_sc1(p + 3)}; }
+// 16-byte store: one instruction per lane (`global_store_dwordx4 ... sc1`; scalar sc1 stores are one fabric write each).
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_sc1_4(float *p, float4 v) {
+  const v4f x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void store_part_sc1(float *rec, int q, int kp, float4 cV, float4 cA, float cw) {
+  st_sc1_4(rec + 4 * q, cV);
+  st_sc1_4(rec + kp + 4 * q, cA);
+  if (q == 0) st_sc1(rec + 2 * kp, cw);
+}
+
 struct FwdArgs {
   const float *rows;
   const int64_t *foff;
@@ -355,12 +375,9 @@ struct FwdArgs {
 // NPASS > 0: the field loop is fully unrolled (F <= NPASS * SLOTS) and every index, value, offset and row load of the
 // sample is issued before the first use, so one wave keeps up to 3 * NPASS row requests in flight.  NPASS == 0: generic.
 template <int LPR, int LAYOUT, int NPASS>
-__global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
+__device__ __forceinline__ void forward_sample(const FwdArgs &a, const int b, const int lane) {
   constexpr int SLOTS = WAVE / LPR;
   constexpr int NP = NPASS > 0 ? NPASS : 1;
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (b >= a.B) return;  // wave-uniform
   const int slot = lane / LPR, q = lane % LPR;
   const int kp = LPR * 4;
 
@@ -465,6 +482,13 @@ __global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
       if (a.out.dz) a.out.dz[(size_t)b * a.ld1] = dz;
     }
   }
+}
+
+template <int LPR, int LAYOUT, int NPASS>
+__global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= a.B) return;  // wave-uniform
+  forward_sample<LPR, LAYOUT, NPASS>(a, b, threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -602,26 +626,6 @@ __device__ __forceinline__ void update_row(float *rp, int q, int kp, int zoff, R
       *reinterpret_cast<float4 *>(rp + kp) = fo;
     }
   }
-}
-
-// Agent-scope relaxed atomic accesses compile to `global_store/load ... sc1` (write-through / L1-bypassing): the form
-// the in-launch hand-off of partial records uses on BOTH sides (MI355X_MICROARCH.md, "Valid forms": every store and every
-// load of the handed-off bytes sc1, the storing wave's s_waitcnt vmcnt(0) before its flag store).
-__device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_sc1(const float *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float4 ld_sc1_4(const float *p) { return {ld_sc1(p), ld_sc1(p + 1), ld_sc1(p + 2), ld_sc1(p + 3)}; }
-__device__ __forceinline__ void store_part_sc1(float *rec, int q, int kp, float4 cV, float4 cA, float cw) {
-  st_sc1(rec + 4 * q, cV.x);
-  st_sc1(rec + 4 * q + 1, cV.y);
-  st_sc1(rec + 4 * q + 2, cV.z);
-  st_sc1(rec + 4 * q + 3, cV.w);
-  st_sc1(rec + kp + 4 * q, cA.x);
-  st_sc1(rec + kp + 4 * q + 1, cA.y);
-  st_sc1(rec + kp + 4 * q + 2, cA.z);
-  st_sc1(rec + kp + 4 * q + 3, cA.w);
-  if (q == 0) st_sc1(rec + 2 * kp, cw);
 }
 
 // partial-sum record: [cV (kp) | cA (kp) | cw, pad3]
@@ -1246,7 +1250,7 @@ Tune &tune() {
 constexpr int SORT_AHEAD_MAX = 8;  // batches sorted per side-stream launch in fmx_fm_stream
 
 // ---- workspace carving: [ sorted u32 F*Bp (x 2*SORT_AHEAD_MAX: the online loop sorts a group of batches ahead) |
-//                          meta i32 F*tiles*2 | parts f32 F*tiles*2*REC ], each 256-byte aligned ----
+//                          meta i32 F*tiles*2 | counter | parts f32 F*tiles*2*REC ], each 256-byte aligned ----
 struct Workspace {
   uint32_t *sorted;       // buffer 0 of a ring of 2 * SORT_AHEAD_MAX buffers, `sorted_stride` elements apart
   size_t sorted_stride;
@@ -1352,6 +1356,14 @@ void launch_forward(const FwdArgs &a, int layout, hipStream_t st) {
   }
 }
 
+// The in-launch hand-offs tag their flag words with a per-launch sequence number passed as a kernel argument; a captured
+// launch would replay a frozen number, so captures take the paths without hand-offs.
+bool is_capturing(hipStream_t st) {
+  if (!st) return false;  // the legacy default stream cannot be captured
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
 template <int LPR, bool HAS_GBI, bool INL>
 void launch_update(const UpdArgs &a, int rule, hipStream_t st) {
   const int tiles = a.F * (a.Bp >> 6);
@@ -1390,7 +1402,7 @@ void launch_fixup(const UpdArgs &a, int rule, hipStream_t st, hipEvent_t stop) {
 
 template <int LPR>
 void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st, hipEvent_t mid, hipEvent_t stop) {
-  if (tune().inline_fixup) {  // one launch: the closing tile of a run that crosses tiles sums the partial records itself
+  if (tune().inline_fixup && !is_capturing(st)) {  // one launch: the closing tile of a run that crosses tiles sums the partial records itself
     if (has_gbi) launch_update<LPR, true, true>(a, rule, st);
     else launch_update<LPR, false, true>(a, rule, st);
     if (mid) (void)hipEventRecord(mid, st);
@@ -1473,8 +1485,8 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
   return check_launch("k_sort_occ");
 }
 
-int forward_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *xv, const float *y,
-                 int32_t B, int32_t loss_kind, float inv_b, const fmx_fwd_out_t *out, hipStream_t st) {
+FwdArgs fill_fwd(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *xv, const float *y,
+                 int32_t B, int32_t loss_kind, float inv_b, const fmx_fwd_out_t *out) {
   FwdArgs a;
   a.ldS = out->sample_ld > 0 ? out->sample_ld : table->kp;
   a.ld1 = out->sample_ld > 0 ? out->sample_ld : 1;
@@ -1494,6 +1506,12 @@ int forward_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32
   a.loss_kind = loss_kind;
   a.h.alpha = 1.0f / hyper->alpha;  // the kernels multiply by 1/alpha
   a.inv_b = inv_b;
+  return a;
+}
+
+int forward_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *xv, const float *y,
+                 int32_t B, int32_t loss_kind, float inv_b, const fmx_fwd_out_t *out, hipStream_t st) {
+  const FwdArgs a = fill_fwd(table, hyper, idx, xv, y, B, loss_kind, inv_b, out);
   switch (lpr_of(table->kp)) {
     case 1: launch_forward<1>(a, table->layout, st); break;
     case 2: launch_forward<2>(a, table->layout, st); break;
@@ -1504,12 +1522,10 @@ int forward_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32
   return check_launch("k_fm_forward");
 }
 
-int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const Workspace &w,
-                const uint32_t *sorted, const float *xv,
-                const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
-                const float *loss_b, float inv_b, float *loss_out, hipStream_t st, hipEvent_t mid,
-                int32_t *step_counter = nullptr, hipEvent_t stop = nullptr, int32_t sample_ld = 0,
-                int32_t *err_flag = nullptr) {
+UpdArgs fill_upd(const fmx_table_t *table, const fmx_hyper_t *hyper, const Workspace &w, const uint32_t *sorted,
+                 const float *xv, const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
+                 const float *loss_b, float inv_b, float *loss_out, int32_t *step_counter, int32_t sample_ld,
+                 int32_t *err_flag) {
   UpdArgs a;
   a.ldS = sample_ld > 0 ? sample_ld : table->kp;
   a.ld1 = sample_ld > 0 ? sample_ld : 1;
@@ -1541,6 +1557,17 @@ int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
   a.zoff = table->z_offset;
   a.h.alpha = 1.0f / hyper->alpha;  // the kernels multiply by 1/alpha
   a.inv_b = inv_b;
+  return a;
+}
+
+int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const Workspace &w,
+                const uint32_t *sorted, const float *xv,
+                const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
+                const float *loss_b, float inv_b, float *loss_out, hipStream_t st, hipEvent_t mid,
+                int32_t *step_counter = nullptr, hipEvent_t stop = nullptr, int32_t sample_ld = 0,
+                int32_t *err_flag = nullptr) {
+  const UpdArgs a = fill_upd(table, hyper, w, sorted, xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out, step_counter,
+                             sample_ld, err_flag);
   switch (lpr_of(table->kp)) {
     case 1: launch_update_pair<1>(a, rule, gbi != nullptr, st, mid, stop); break;
     case 2: launch_update_pair<2>(a, rule, gbi != nullptr, st, mid, stop); break;
@@ -1674,7 +1701,7 @@ int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
     if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
   }
   return update_impl(table, hyper, rule, w, w.sorted, xv, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b, loss_out, st,
-                     nullptr, nullptr, nullptr, 0, fwd->error);
+                     nullptr, nullptr, nullptr, fwd->sample_ld, fwd->error);
 }
 
 int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
@@ -1750,15 +1777,25 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
         if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
         if (rc == FMX_OK)
           rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                           loss_out, st, nullptr, loss_out ? w.counter : nullptr, nullptr, 0, fwd->error);
+                           loss_out, st, nullptr, loss_out ? w.counter : nullptr, nullptr, fwd->sample_ld, fwd->error);
       }
       if (sd) (void)hipEventRecord(sd->consumed[g & 1], st);
     }
     return rejoin(rc);
   }
 
-  // timing mode: everything on `stream`, HIP events around every kernel
-  const int n_ev = 5;
+  // timing mode: everything on `stream`.  An event pair costs several microseconds of its own on this stack (slot 3
+  // measures exactly that: two records with nothing between), so each kernel is launched REP times back to back between
+  // two events and the pair's own cost is subtracted: per-launch figures that agree with rocprofv3's kernel trace.
+  // Repeating is harmless: the sort and the forward are idempotent, the update just applies the same step REP times.
+  const int n_ev = 5, REP = 8;
+  hipStream_t user_t = st;
+  Side *sdt = (st == nullptr) ? side_for_current_device() : nullptr;  // same detour off the legacy stream as above
+  if (sdt) {
+    (void)hipEventRecord(sdt->user_fork, user_t);
+    st = sdt->main;
+    (void)hipStreamWaitEvent(st, sdt->user_fork, 0);
+  }
   hipEvent_t *ev = new hipEvent_t[(size_t)n_steps * n_ev];
   for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventCreate(&ev[i]);
   for (int s = 0; s < n_steps && rc == FMX_OK; ++s) {
@@ -1767,24 +1804,32 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     const float *y = y_pool + (size_t)j * B;
     hipEvent_t *e = ev + (size_t)s * n_ev;
     (void)hipEventRecord(e[0], st);
-    rc = sort_impl(table, idx, B, w.sorted, fwd->error, st);
+    for (int r = 0; r < REP && rc == FMX_OK; ++r) rc = sort_impl(table, idx, B, w.sorted, fwd->error, st);
     (void)hipEventRecord(e[1], st);
-    if (rc == FMX_OK) rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
+    for (int r = 0; r < REP && rc == FMX_OK; ++r) rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
     (void)hipEventRecord(e[2], st);
-    if (rc == FMX_OK)
+    for (int r = 0; r < REP && rc == FMX_OK; ++r)
       rc = update_impl(table, hyper, rule, w, w.sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                       loss_out ? loss_out + s : nullptr, st, e[3]);
+                       loss_out ? loss_out + s : nullptr, st, nullptr, nullptr, nullptr, fwd->sample_ld, fwd->error);
+    (void)hipEventRecord(e[3], st);
     (void)hipEventRecord(e[4], st);
   }
   (void)hipStreamSynchronize(st);
+  if (sdt) {
+    (void)hipEventRecord(sdt->user_join, st);
+    (void)hipStreamWaitEvent(user_t, sdt->user_join, 0);
+  }
   for (int k = 0; k < 4; ++k) kernel_ms[k] = 0.f;
   if (rc == FMX_OK) {
     for (int s = 0; s < n_steps; ++s) {
       hipEvent_t *e = ev + (size_t)s * n_ev;
-      for (int k = 0; k < 4; ++k) {
+      float pair = 0.f;
+      (void)hipEventElapsedTime(&pair, e[3], e[4]);
+      kernel_ms[3] += pair;
+      for (int k = 0; k < 3; ++k) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e[k], e[k + 1]);
-        kernel_ms[k] += ms;
+        kernel_ms[k] += fmaxf(ms - pair, 0.f) / REP;
       }
     }
   }

@@ -149,7 +149,7 @@ class FMEngine:
                                         C.byref(out), self.loss_out.data_ptr(), self._stream()))
 
     def stream(self, hyper, rule, loss, idx_pool, y_pool, n_steps, loss_out=None, timed=False):
-        """The online loop over a resident pool of batches (fmx_fm_stream).  Returns per-kernel ms when timed."""
+        """The online loop over a resident pool of batches (fmx_fm_stream).  Returns per-launch ms [sort, forward, update, empty event pair] when timed (the measuring mode repeats launches: see fmx.h)."""
         n_pool, B, F = idx_pool.shape
         assert F == self.table.n_fields and y_pool.shape == (n_pool, B)
         self._ensure(B)

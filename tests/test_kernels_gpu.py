@@ -364,7 +364,8 @@ def test_full_size_criteo(fmx, rule):
 
 
 def test_stream_matches_repeated_steps(fmx):
-    """fmx_fm_stream over a pool == the same steps issued one by one; the timed variant returns kernel times."""
+    """fmx_fm_stream over a pool == the same steps issued one by one; the measuring variant (which repeats every launch,
+    so its table is not compared) returns kernel times."""
     sizes, k, B, n_pool, n_steps = MIXED_SIZES, 16, 512, 3, 7
     prs = [make_problem(sizes, k, B, seed=40 + j) for j in range(n_pool)]
     hyp = fmx.Hyper(**HYP)
@@ -384,10 +385,13 @@ def test_stream_matches_repeated_steps(fmx):
         loss_out = torch.zeros(n_steps, device="cuda")
         ms = e2.stream(hyp, "signadam", "logits", idx_pool, y_pool, n_steps, loss_out, timed=timed)
         torch.cuda.synchronize()
-        np.testing.assert_array_equal(t1.rows.cpu().numpy(), t2.rows.cpu().numpy())
-        np.testing.assert_array_equal(np.asarray(losses1, dtype=np.float32), loss_out.cpu().numpy())
+        e2.check_error_flag()
         if timed:
             assert len(ms) == 4 and all(v > 0 for v in ms)
+            assert np.isfinite(t2.rows.cpu().numpy()).all()
+            continue
+        np.testing.assert_array_equal(t1.rows.cpu().numpy(), t2.rows.cpu().numpy())
+        np.testing.assert_array_equal(np.asarray(losses1, dtype=np.float32), loss_out.cpu().numpy())
 
 
 def test_abi_rejects_bad_arguments(fmx):
@@ -482,8 +486,8 @@ def test_inline_fixup_and_second_launch_give_identical_bits(fmx, zipf):
     V0 = torch.from_numpy((rng.normal(size=(R, k)) * 0.05).astype(np.float32)).cuda()
     res = []
     lib = fmx._lib.load()
-    for mode in (1, 0):
-        prev = lib.fmx_set_option(b"inline_fixup", mode)
+    for inline in (1, 0):
+        prev = lib.fmx_set_option(b"inline_fixup", inline)
         try:
             t = fmx.FlatTable(sizes, k, layout="ftrl", ftrl=HYP)
             t.rows[:, :k] = V0
@@ -499,3 +503,34 @@ def test_inline_fixup_and_second_launch_give_identical_bits(fmx, zipf):
     for a, b in zip(res[0], res[1]):
         np.testing.assert_array_equal(a, b)
     assert np.isfinite(res[0][2]).all()
+
+
+@pytest.mark.parametrize("k,B,rule", [(4, 37, "sgd"), (8, 300, "signadam"), (16, 1000, "ftrl"), (32, 129, "ftrl"), (64, 64, "sgd")])
+def test_inline_fixup_matches_second_launch_small_shapes(fmx, k, B, rule):
+    """The same identity for every lane layout (kp = 4..64), ragged batch sizes and feature values != 1, through fmx_fm_step."""
+    sizes = MIXED_SIZES
+    lib = fmx._lib.load()
+    res = []
+    for inline in (1, 0):
+        prev = lib.fmx_set_option(b"inline_fixup", inline)
+        try:
+            pr = make_problem(sizes, k, B, seed=5, real_x=True)
+            if rule == "ftrl":
+                t = fmx.FlatTable(sizes, k, layout="ftrl", ftrl=HYP)
+                V0 = torch.from_numpy(pr["V"]).cuda()
+                t.rows[:, :k] = V0
+                t.rows[:, t.z_offset:t.z_offset + k] = fmx.table.ftrl_z_for_weight_torch(V0, t.ftrl)
+            else:
+                t = weights_table(fmx, sizes, k, pr)
+            eng = fmx.FMEngine(t, max_batch=B)
+            idx_d, xv_d, y_d = eng.to_device(pr["idx"], pr["x"], pr["y"])
+            losses = []
+            for _ in range(5):
+                eng.step(fmx.Hyper(**HYP), rule, "logits", idx_d, xv_d, y_d)
+                losses.append(float(eng.loss_out.item()))
+            eng.check_error_flag()
+            res.append((t.rows.cpu().numpy(), t.bias.cpu().numpy(), np.asarray(losses)))
+        finally:
+            lib.fmx_set_option(b"inline_fixup", prev)
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, b)
