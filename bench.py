@@ -142,8 +142,8 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05) indices instead of uniform (secondary workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--row-stride", type=int, default=0)

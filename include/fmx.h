@@ -118,8 +118,11 @@ int fmx_sorted_bbits(int B);
 /* Bytes of caller-owned device workspace a step of batch size B needs (16-byte aligned).  Layout:
  *   sorted  uint32 [16][F, Bp]       occurrence lists: (local index << bbits) | sample, padded with 0xFFFFFFFF
  *                                    (a ring of 16: fmx_fm_stream sorts up to 8 batches ahead; single steps use the first)
- *   meta    int32  [F, Bp/64, 2]     per 64-entry tile: does a run come in from / go out to the neighbouring tile
+ *   meta    int32  [F, Bp/64, 2]     per 64-entry tile: does a run come in from / go out to the neighbouring tile; with the
+ *                                    in-launch hand-off word 0 is (launch sequence << 4 | states) and is polled by later tiles
  *   parts   float  [F, Bp/64, 2, 2*kp+4]  partial sums of the runs that cross a tile boundary
+ * The workspace must be ZERO-FILLED once before its first use (the hand-off's flag words are compared with a
+ * non-zero launch sequence number; never-written words must not match one by accident).
  * Negative on a bad table. */
 int64_t fmx_workspace_bytes(const fmx_table_t *table, int32_t B);
 
