@@ -81,7 +81,8 @@ def cpu_baseline(idx_pool, y_pool, sizes, seconds=15.0):
 
 def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
     """BASELINE configs[3]: online DeepFM (bi-interaction + 3 x 256 relu MLP, SGD lr 1e-3) on the same synthetic Criteo
-    stream, exact data parallelism (fmx.DeepFMTrainer).  The MLP runs in PyTorch (rocBLAS GEMMs) this round."""
+    stream, exact data parallelism (fmx.DeepFMTrainer).  The MLP section is fmx_mlp_section (fp32 MFMA GEMMs);
+    FMX_MLP_NATIVE=0 runs it through PyTorch autograd instead (rocBLAS; FMX_MLP_GRAPH=1 replays it as a graph)."""
     import torch.nn as nn
     lr, hidden, n_layers = 1e-3, 256, 3
     table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="weights", device=dev)
@@ -91,7 +92,8 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
     layers = [nn.Linear(K_EMB if j == 0 else hidden, hidden).to(dev) for j in range(n_layers)]
     eng = fmx.FMEngine(table, max_batch=BATCH * world)
     tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=lr), "sgd"), layers, K_EMB, table.kp, mlp_lr=lr,
-                           use_graph=os.environ.get("FMX_MLP_GRAPH", "1") == "1")
+                           use_graph=os.environ.get("FMX_MLP_GRAPH", "1") == "1",
+                           native_mlp=os.environ.get("FMX_MLP_NATIVE", "1") == "1")
     idx_np, y_np = synth_pool(N_POOL, BATCH, CRITEO_SIZES, SEED + 1000 * rank, zipf=args.zipf)
     idx_pool, y_pool = torch.from_numpy(idx_np).to(dev), torch.from_numpy(y_np).to(dev)
 
@@ -130,7 +132,8 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
         "metric": "samples/sec online-DeepFM (Criteo-39-field, k=16, 3x256 relu MLP) SGD", "value": steps * BATCH * world / dt,
         "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "online DeepFM fwd+bwd, fused SGD row update of the tables, PyTorch MLP 16-256-256-256 "
+        "config": {"workload": "online DeepFM fwd+bwd, fused SGD row update of the tables, "
+                               + ("fp32-MFMA" if tr.native else "PyTorch") + " MLP 16-256-256-256 "
                                f"({mlp_params} parameters, {mlp_params * 4} B all-reduced per step when N > 1), synthetic "
                                f"Criteo-39 (R=1,006,628, k=16, B={BATCH} per GPU); BASELINE.json configs[3]",
                    "global_batch": BATCH * world,

@@ -1262,6 +1262,8 @@ struct Workspace {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+#include "fmx_mlp_gemm.inc"
+
 Workspace carve(const fmx_table_t *t, int B, void *base) {
   const size_t F = (size_t)t->n_fields, Bp = (size_t)fmx_sorted_width(B), tiles = Bp >> 6;
   const size_t rec = 2 * (size_t)t->kp + 4;
@@ -1904,6 +1906,164 @@ int fmx_mlp_hedge_fit(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge
   a.mode = MLP_MODE_HEDGE;
   a.inv_b = 1.0f / (float)B;
   return mlp_launch(mlp, a, B, kp, stream, "fmx_mlp_hedge_fit");
+}
+
+int64_t fmx_mlp_section_workspace_bytes(const fmx_mlp_t *mlp, int32_t B) {
+  if (!mlp || mlp->n_layers < 1 || mlp->n_layers > MLP_BIG_MAX_L || mlp->k < 1 || mlp->hidden < 1 || B < 1)
+    return fail(FMX_ERR_ARG, "fmx_mlp_section_workspace_bytes: bad mlp / B");
+  return (int64_t)mlp_big_carve(mlp, B, nullptr).bytes;
+}
+
+int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, int32_t ld_bi, const float *base,
+                    const float *y, int32_t B, float inv_b, void *workspace, float *logit_out, float *dz_out,
+                    float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply, float *loss_out, fmx_stream_t stream) {
+  if (!mlp || !mlp->params || !bi || !base || !y || !workspace || !dz_out || !gbi_out || !grads)
+    return fail(FMX_ERR_ARG, "fmx_mlp_section: null argument");
+  if (mlp->n_layers < 1 || mlp->n_layers > MLP_BIG_MAX_L || mlp->k < 1 || mlp->hidden < 1 || B < 1)
+    return fail(FMX_ERR_UNSUPPORTED, "fmx_mlp_section: needs 1 <= layers <= %d, k >= 1, hidden >= 1, B >= 1", MLP_BIG_MAX_L);
+  if (ld_bi < mlp->k || ld_gbi < mlp->k) return fail(FMX_ERR_SHAPE, "fmx_mlp_section: ld_bi / ld_gbi smaller than k");
+  if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "fmx_mlp_section needs a loss");
+  if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const MlpBigWs w = mlp_big_carve(mlp, B, workspace);
+  const int L = mlp->n_layers, H = mlp->hidden, k = mlp->k;
+  const size_t act = align_up((size_t)B * H * 4, 256) / 4;
+  const float *Wl[MLP_BIG_MAX_L], *bl[MLP_BIG_MAX_L];
+  long long off[MLP_BIG_MAX_L];
+  {
+    long long o = 0;
+    for (int l = 0; l < L; ++l) {
+      const int in = l == 0 ? k : H;
+      off[l] = o;
+      Wl[l] = mlp->params + o;
+      bl[l] = mlp->params + o + (long long)H * in;
+      o += (long long)H * in + H;
+    }
+  }
+  auto base_args = [] {
+    GemmArgs g;
+    g.bias = nullptr;
+    g.mask = nullptr;
+    g.ldmask = 0;
+    g.c_split_stride = 0;
+    g.ones_col = -1;
+    g.zero_cols_to = 0;
+    return g;
+  };
+  // ---- forward ----
+  for (int l = 0; l < L; ++l) {
+    const int in = l == 0 ? k : H;
+    GemmArgs g = base_args();
+    g.A = l == 0 ? bi : w.acts + (size_t)(l - 1) * act;
+    g.lda = l == 0 ? ld_bi : H;
+    g.Bm = Wl[l];
+    g.ldb = in;
+    g.C = w.acts + (size_t)l * act;
+    g.ldc = H;
+    g.bias = bl[l];
+    g.M = B;
+    g.N = H;
+    g.K = in;
+    g.k_chunk = in;
+    g.vecA = vec_ok(g.A, g.lda);
+    g.vecB = vec_ok(g.Bm, g.ldb);
+    launch_gemm<0, 1, EPI_BIAS_RELU>(g, 1, st);
+  }
+  // ---- loss, dL/dlogit, dH_L ----
+  {
+    MlpLossArgs a;
+    a.H = w.acts + (size_t)(L - 1) * act;
+    a.dH = w.dHa;
+    a.base = base;
+    a.y = y;
+    a.out = logit_out;
+    a.dz = dz_out;
+    a.loss_b = w.loss_b;
+    a.B = B;
+    a.hidden = H;
+    a.ldh = H;
+    a.loss_kind = loss_kind;
+    a.inv_b = inv_b;
+    hipLaunchKernelGGL(k_mlp_loss, dim3((B + 3) / 4), dim3(256), 0, st, a);
+  }
+  // ---- backward ----
+  float *cur = w.dHa, *nxt = w.dHb;
+  for (int l = L - 1; l >= 0; --l) {
+    const int in = l == 0 ? k : H;
+    const float *prev = l == 0 ? bi : w.acts + (size_t)(l - 1) * act;
+    const int ldprev = l == 0 ? ld_bi : H;
+    {  // dW_l | db_l = dH_l^T . [H_{l-1} | 1], split over the batch
+      GemmArgs g = base_args();
+      g.A = cur;
+      g.lda = H;
+      g.Bm = prev;
+      g.ldb = ldprev;
+      g.C = w.parts[l];
+      g.ldc = w.ldp[l];
+      g.M = H;
+      g.N = in + 1;
+      g.K = B;
+      g.k_chunk = 256;
+      g.c_split_stride = (long long)H * w.ldp[l];
+      g.ones_col = in;
+      g.vecA = vec_ok(g.A, g.lda);
+      g.vecB = vec_ok(g.Bm, g.ldb);
+      launch_gemm<1, 0, EPI_NONE>(g, w.n_split, st);
+    }
+    GemmArgs g = base_args();
+    g.A = cur;
+    g.lda = H;
+    g.Bm = Wl[l];
+    g.ldb = in;
+    g.M = B;
+    g.N = in;
+    g.K = H;
+    g.k_chunk = H;
+    g.vecA = vec_ok(g.A, g.lda);
+    g.vecB = vec_ok(g.Bm, g.ldb);
+    if (l > 0) {  // dH_{l-1} = (dH_l . W_l) * (H_{l-1} > 0)
+      g.C = nxt;
+      g.ldc = H;
+      g.mask = prev;
+      g.ldmask = H;
+      launch_gemm<0, 0, EPI_MASK>(g, 1, st);
+      float *tmp = cur;
+      cur = nxt;
+      nxt = tmp;
+    } else {  // dL/dbi through the MLP, padding columns zeroed
+      g.C = gbi_out;
+      g.ldc = ld_gbi;
+      g.zero_cols_to = ld_gbi;
+      launch_gemm<0, 0, EPI_NONE>(g, 1, st);
+    }
+  }
+  // ---- partials -> flat gradients (+ optional SGD), mean loss ----
+  {
+    MlpReduceArgs a;
+    long long biggest = 0;
+    for (int l = 0; l < MLP_BIG_MAX_L; ++l) {
+      const int in = l == 0 ? k : H;
+      a.parts[l] = l < L ? w.parts[l] : nullptr;
+      a.out_dim[l] = H;
+      a.in_dim[l] = in;
+      a.ldp[l] = l < L ? w.ldp[l] : 0;
+      a.grad_off[l] = l < L ? off[l] : 0;
+      if (l < L && (long long)H * (in + 1) > biggest) biggest = (long long)H * (in + 1);
+    }
+    a.grads = grads;
+    a.params = mlp->params;
+    a.lr = lr_apply;
+    a.n_split = w.n_split;
+    a.n_layers = L;
+    a.loss_b = w.loss_b;
+    a.loss_out = loss_out;
+    a.B = B;
+    a.inv_b = 1.0f;  // the per-sample losses are summed; the caller's inv_b is already in dz, and the loss is sum * inv_b:
+    a.inv_b = inv_b;
+    const int bx = (int)((biggest + 255) / 256);
+    hipLaunchKernelGGL(k_mlp_reduce, dim3(bx > 256 ? 256 : bx, L), dim3(256), 0, st, a);
+  }
+  return check_launch("fmx_mlp_section");
 }
 
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream) {

@@ -15,7 +15,8 @@ RULES = {"signadam": RULE_SIGNADAM, "sgd": RULE_SGD, "ftrl": RULE_FTRL}
 LOSSES = {None: LOSS_NONE, "none": LOSS_NONE, "logits": LOSS_BCE_LOGITS, "sigmoid": LOSS_BCE_SIGMOID}
 
 EXPORTS = ["fmx_version", "fmx_last_error_string", "fmx_set_option", "fmx_sorted_width", "fmx_sorted_bbits", "fmx_workspace_bytes",
-           "fmx_fm_forward", "fmx_mlp_forward", "fmx_mlp_fit", "fmx_mlp_hedge_fit",
+           "fmx_fm_forward", "fmx_mlp_forward", "fmx_mlp_fit", "fmx_mlp_hedge_fit", "fmx_mlp_section",
+           "fmx_mlp_section_workspace_bytes",
            "fmx_sort_occurrences", "fmx_fm_update", "fmx_fm_step", "fmx_fm_stream", "fmx_stream_read"]
 
 
@@ -76,6 +77,9 @@ def load():
     lib.fmx_mlp_forward.argtypes = [MP, p, i32, p, i32, p, p, p]
     lib.fmx_mlp_fit.argtypes = [MP, HP, i32, i32, p, i32, p, p, i32, f32, p, p, p, p]
     lib.fmx_mlp_hedge_fit.argtypes = [MP, f32, f32, f32, p, p, i32, p, p, i32, p, p]
+    lib.fmx_mlp_section_workspace_bytes.restype = C.c_int64
+    lib.fmx_mlp_section_workspace_bytes.argtypes = [MP, i32]
+    lib.fmx_mlp_section.argtypes = [MP, i32, p, i32, p, p, i32, f32, p, p, p, p, i32, p, f32, p, p]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name == "fmx_workspace_bytes":

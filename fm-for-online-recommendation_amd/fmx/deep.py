@@ -3,8 +3,9 @@
 
 Per step and rank (B local samples, G ranks, everything scaled by 1 / (G B) so that the result is the G B-sample step):
   1. forward of the tables on the local slice (k_fm_forward): S, bi, FM logit
-  2. the MLP on bi (PyTorch: at 3 x 256 it is a plain GEMM chain; a fused kernel exists only for the small online
-     shapes, fmx_mlp_fit) -> loss, dL/dlogit, dL/dbi, local MLP gradients
+  2. the MLP on bi (fmx_mlp_section: fp32 MFMA GEMMs for forward, loss and backward; a PyTorch autograd form of the same
+     section is kept as the tests' comparison and for networks with unequal layer widths)
+     -> loss, dL/dlogit, dL/dbi, local MLP gradients
   3. ONE fused all-reduce (sum) of the flattened MLP gradients            -- the dense exchange
   4. all-gather of the low-rank factors of the row gradients (idx, S, dz, dL/dbi)  -- 288 B per sample, no rows move
   5. identical sort + row-reduced table update on every replica (k_sort_occ, k_fm_update, k_fm_fixup), SGD on the MLP
@@ -30,6 +31,9 @@ class HipDeepBackend:
     def bias(self):
         return self.e.table.bias_weight()
 
+    def mlp_section(self, flat, gflat, k, hidden, n_layers, loss, bi, base, y, inv_b, lr_apply):
+        return self.e.mlp_section(flat, gflat, k, hidden, n_layers, loss, bi, base, y, bi.shape[0], inv_b, lr_apply)
+
     def update(self, idx_g, S_g, dz_g, gbi_g, fm_term, inv_b):
         e = self.e
         GB = idx_g.shape[0]
@@ -39,15 +43,30 @@ class HipDeepBackend:
 
 
 class DeepFMTrainer:
-    def __init__(self, backend, hidden_layers, k, kp, mlp_lr, fm_term=True, loss="logits", group=None, use_graph=False):
+    def __init__(self, backend, hidden_layers, k, kp, mlp_lr, fm_term=True, loss="logits", group=None, use_graph=False,
+                 native_mlp=True):
         """hidden_layers: list of nn.Linear on the device (k -> H -> ... -> H); the network's logit contribution is the
-        sum of the last activation (reference deepfm_adam.py:82-88).  fm_term=False gives NFM (nfm_adam.py:78-88)."""
+        sum of the last activation (reference deepfm_adam.py:82-88).  fm_term=False gives NFM (nfm_adam.py:78-88).
+        native_mlp: run the MLP section through fmx_mlp_section (needs a backend that has it and equal layer widths);
+        otherwise PyTorch autograd, optionally replayed as a graph (use_graph)."""
         self.backend, self.layers, self.k, self.kp = backend, list(hidden_layers), k, kp
         self.mlp_lr, self.fm_term, self.loss, self.group = mlp_lr, fm_term, loss, group
-        self.use_graph = use_graph      # replay the MLP section as a captured graph (static batch size)
+        self.use_graph = use_graph      # replay the PyTorch MLP section as a captured graph (static batch size)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = [p for layer in self.layers for p in (layer.weight, layer.bias)]
         self._bufs = {}
+        widths = {layer.out_features for layer in self.layers} | {layer.in_features for layer in self.layers[1:]}
+        self.native = bool(native_mlp and hasattr(backend, "mlp_section") and len(widths) == 1 and
+                           self.layers[0].in_features == k and len(self.layers) <= 8 and self.params[0].is_cuda)
+        if self.native:   # one flat buffer (W_l then b_l per layer) that the nn.Linear parameters become views of
+            self.hidden = self.layers[0].out_features
+            self.flat = torch.cat([p.detach().reshape(-1) for p in self.params]).contiguous()
+            self.gflat = torch.zeros_like(self.flat)
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                p.data = self.flat[off:off + n].view_as(p)
+                off += n
 
     def _gathered(self, name, local):
         if self.world == 1:
@@ -115,8 +134,16 @@ class DeepFMTrainer:
         idx_g = self._gathered("idx", idx_local)
         S, bi, sfirst, logit_fm = self.backend.forward(idx_local)
         base_in = logit_fm if self.fm_term else sfirst + self.backend.bias()
-        section = self._mlp_section_graphed if (self.use_graph and bi.is_cuda) else self._mlp_section
-        loss, dz, gbi, flat = section(bi[:, :self.k], base_in, y_local, inv_b)
+        applied = False
+        if self.native:
+            applied = self.world == 1      # single rank: SGD on the MLP inside the reduction kernel
+            loss, dz, gbi = self.backend.mlp_section(self.flat, self.gflat, self.k, self.hidden, len(self.layers), self.loss,
+                                                     bi, base_in.contiguous(), y_local, inv_b,
+                                                     self.mlp_lr if applied else 0.0)
+            loss, flat = loss[0], self.gflat
+        else:
+            section = self._mlp_section_graphed if (self.use_graph and bi.is_cuda) else self._mlp_section
+            loss, dz, gbi, flat = section(bi[:, :self.k], base_in, y_local, inv_b)
         # ---- the dense exchange: one bucket ----
         if self.world > 1:
             if flat.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -130,6 +157,10 @@ class DeepFMTrainer:
         dz_g = self._gathered("dz", dz)
         gbi_g = self._gathered("gbi", gbi)
         self.backend.update(idx_g, S_g.contiguous(), dz_g.contiguous(), gbi_g, self.fm_term, inv_b)
+        if self.native:
+            if not applied:
+                self.flat.sub_(flat, alpha=self.mlp_lr)
+            return loss
         with torch.no_grad():
             off = 0
             for p in self.params:

@@ -198,6 +198,26 @@ class FMEngine:
         _lib.check(self.lib.fmx_mlp_hedge_fit(C.byref(m), lr, hedge_b, hedge_s, alpha.data_ptr(), self.bi.data_ptr(),
                                               self.table.kp, base.data_ptr(), y_d.data_ptr(), B, None, self._stream()))
 
+    def mlp_section(self, params, grads, k, hidden, n_layers, loss, bi, base, y_d, B, inv_b, lr_apply=0.0):
+        """The MLP on `bi` at mini-batch sizes (fmx_mlp_section: fp32 MFMA GEMMs): forward, loss, backward.
+        -> (loss [1], dz [B], gbi [B, kp]); `grads` (flat, the layout of `params`) is filled; lr_apply != 0 also applies SGD."""
+        m = self._mlp_struct(params, k, hidden, n_layers)
+        key = (k, hidden, n_layers, B)
+        if getattr(self, "_mlp_ws_key", None) != key:
+            nbytes = int(self.lib.fmx_mlp_section_workspace_bytes(C.byref(m), B))
+            if nbytes < 0:
+                raise _lib.FmxError(nbytes, self.lib.fmx_last_error_string().decode())
+            self._mlp_ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            self._mlp_dz = torch.empty(B, dtype=torch.float32, device=self.device)
+            self._mlp_gbi = torch.empty((B, self.table.kp), dtype=torch.float32, device=self.device)
+            self._mlp_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._mlp_ws_key = key
+        _lib.check(self.lib.fmx_mlp_section(C.byref(m), _lib.LOSSES[loss], bi.data_ptr(), bi.stride(0), base.data_ptr(),
+                                            y_d.data_ptr(), B, inv_b, self._mlp_ws.data_ptr(), None, self._mlp_dz.data_ptr(),
+                                            self._mlp_gbi.data_ptr(), self.table.kp, grads.data_ptr(), lr_apply,
+                                            self._mlp_loss.data_ptr(), self._stream()))
+        return self._mlp_loss, self._mlp_dz, self._mlp_gbi
+
     def check_error_flag(self):
         if int(self.error.item()) != 0:
             self.error.zero_()

@@ -219,6 +219,21 @@ int fmx_mlp_fit(const fmx_mlp_t *mlp, const fmx_hyper_t *hyper, int32_t rule, in
 int fmx_mlp_hedge_fit(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge_s, float *alpha, const float *bi, int32_t kp,
                       const float *base, const float *y, int32_t B, float *losses_out, fmx_stream_t stream);
 
+/* The same network at mini-batch sizes (BASELINE configs[3]: 3 x 256, B = 4096), any B / hidden / k, up to 8 layers:
+ * forward, loss on (base + sum_j x_L[j]), backward -- fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32: exact f32 products and
+ * accumulation), deterministic (split-K partials summed in a fixed order, no atomics).
+ *   bi [B, ld_bi] (first k columns used), base [B], y [B];  logit_out [B] may be null
+ *   dz_out [B] = dL/dlogit (inv_b folded in), gbi_out [B, ld_gbi] = dL/dbi through the MLP (columns k..ld_gbi-1 zeroed)
+ *   grads: flat, the layout of mlp->params (W_l [out, in] then b_l [out] per layer); lr_apply != 0 also applies
+ *   params -= lr_apply * grads in the same pass (single-rank SGD); loss_out [1] = inv_b * sum of the per-sample losses
+ *   workspace: fmx_mlp_section_workspace_bytes(mlp, B) bytes, 16-byte aligned (activations, dH ping-pong, split partials)
+ * Replaces: the MLP part of DeepFMAdam.fit / NFMAdam.fit at batch sizes the one-workgroup kernel does not take
+ * (reference deepfm_adam.py:79-89,106-119; nfm_adam.py:78-88,105-118), i.e. nn.Linear + relu + autograd. */
+int64_t fmx_mlp_section_workspace_bytes(const fmx_mlp_t *mlp, int32_t B);
+int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, int32_t ld_bi, const float *base,
+                    const float *y, int32_t B, float inv_b, void *workspace, float *logit_out, float *dz_out,
+                    float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply, float *loss_out, fmx_stream_t stream);
+
 /* Streaming read of `bytes` (multiple of 16) with 16-byte loads; sink [1] receives a checksum so the loads stay
  * live.  Used by bench.py to measure the HBM-read ceiling on the same GPU in the same run. */
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream);

@@ -1,0 +1,109 @@
+"""fmx_mlp_section (the relu MLP at mini-batch sizes: fp32 MFMA GEMMs for forward, loss, backward) against a float64
+PyTorch autograd reference of the same network (reference deepfm_adam.py:79-89,106-119: nn.Linear + relu + autograd).
+Tolerance: fp32 sums over up to 4096 samples in a different order than the reference -> 2e-5 relative to the largest
+magnitude of each output."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fmx():
+    import fmx as _fmx
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _fmx
+
+
+CASES = [  # B, k, kp, hidden, layers, loss
+    (4096, 16, 16, 256, 3, "logits"),       # BASELINE configs[3]
+    (300, 10, 12, 40, 2, "sigmoid"),        # reference embedding size, ragged tiles, the double-sigmoid loss
+    (37, 4, 4, 33, 1, "logits"),            # odd hidden: the scalar-load path; one layer
+    (1000, 16, 16, 64, 5, "logits"),        # the reference's depth
+    (4096, 16, 20, 256, 3, "logits"),       # bi rows strided (records), gbi padded
+]
+
+
+def reference(params, k, H, L, loss, bi, base, y, inv_b):
+    p = params.double().cpu()
+    bi = bi.double().cpu().requires_grad_(True)
+    base = base.double().cpu().requires_grad_(True)
+    Ws, bs, off = [], [], 0
+    for l in range(L):
+        i = k if l == 0 else H
+        Ws.append(p[off:off + H * i].view(H, i).clone().requires_grad_(True)); off += H * i
+        bs.append(p[off:off + H].clone().requires_grad_(True)); off += H
+    x = bi
+    for W, b in zip(Ws, bs):
+        x = F.relu(x @ W.t() + b)
+    out = base + x.sum(1)
+    z = torch.sigmoid(out) if loss == "sigmoid" else out
+    ls = F.binary_cross_entropy_with_logits(z, y.double().cpu(), reduction="sum") * inv_b
+    ls.backward()
+    flat = torch.cat([t.grad.reshape(-1) for pair in zip(Ws, bs) for t in pair])
+    return float(ls), base.grad.numpy(), bi.grad.numpy(), flat.numpy(), out.detach().numpy()
+
+
+def close(a, b, what, rel=2e-5):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max()
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("B,k,kp,H,L,loss", CASES)
+def test_mlp_section_vs_autograd(fmx, B, k, kp, H, L, loss):
+    torch.manual_seed(B + H + L)
+    n_par = sum(H * (k if l == 0 else H) + H for l in range(L))
+    params = (torch.randn(n_par) * (1.0 / np.sqrt(H))).cuda()
+    bi_full = torch.zeros(B, kp)
+    bi_full[:, :k] = torch.randn(B, k) * 0.5
+    bi_d = bi_full.cuda()
+    base = (torch.randn(B) * 0.3).cuda()
+    y = (torch.rand(B) < 0.3).float().cuda()
+    inv_b = 1.0 / B
+    grads = torch.zeros_like(params)
+    import ctypes as C
+    lib = fmx._lib.load()
+    m = fmx._lib.Mlp(params.data_ptr(), L, k, H, 0)
+    ws = torch.empty(int(lib.fmx_mlp_section_workspace_bytes(C.byref(m), B)) // 4, device="cuda")
+    dz = torch.empty(B, device="cuda")
+    gbi = torch.full((B, kp), 7.0, device="cuda")
+    logit = torch.empty(B, device="cuda")
+    loss_out = torch.zeros(1, device="cuda")
+    p0 = params.clone()
+    fmx._lib.check(lib.fmx_mlp_section(C.byref(m), fmx._lib.LOSSES[loss], bi_d.data_ptr(), kp, base.data_ptr(), y.data_ptr(), B,
+                                       inv_b, ws.data_ptr(), logit.data_ptr(), dz.data_ptr(), gbi.data_ptr(), kp,
+                                       grads.data_ptr(), 0.0, loss_out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    r_loss, r_dz, r_gbi, r_flat, r_out = reference(params, k, H, L, loss, bi_d[:, :k], base, y, inv_b)
+    close(logit.cpu().numpy(), r_out, "logit")
+    close(loss_out.item(), r_loss, "loss")
+    close(dz.cpu().numpy(), r_dz, "dz")
+    close(gbi.cpu().numpy()[:, :k], r_gbi, "gbi")
+    assert (gbi.cpu().numpy()[:, k:] == 0).all(), "padding columns of gbi must be zeroed"
+    close(grads.cpu().numpy(), r_flat, "flat gradients")
+    assert torch.equal(params, p0), "lr_apply = 0 must leave the parameters alone"
+    # determinism + the fused SGD application
+    grads2 = torch.zeros_like(params)
+    fmx._lib.check(lib.fmx_mlp_section(C.byref(m), fmx._lib.LOSSES[loss], bi_d.data_ptr(), kp, base.data_ptr(), y.data_ptr(), B,
+                                       inv_b, ws.data_ptr(), None, dz.data_ptr(), gbi.data_ptr(), kp,
+                                       grads2.data_ptr(), 0.25, loss_out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(grads, grads2), "two runs must give identical bits"
+    np.testing.assert_array_equal((p0 - 0.25 * grads).cpu().numpy(), params.cpu().numpy())
+
+
+def test_mlp_section_rejects_bad_arguments(fmx):
+    import ctypes as C
+    lib = fmx._lib.load()
+    params = torch.zeros(100, device="cuda")
+    m = fmx._lib.Mlp(params.data_ptr(), 9, 4, 8, 0)           # too many layers
+    assert lib.fmx_mlp_section_workspace_bytes(C.byref(m), 16) < 0
+    m = fmx._lib.Mlp(params.data_ptr(), 1, 4, 8, 0)
+    x = torch.zeros(64, device="cuda")
+    rc = lib.fmx_mlp_section(C.byref(m), fmx._lib.LOSSES["logits"], x.data_ptr(), 2, x.data_ptr(), x.data_ptr(), 4, 0.25,
+                             x.data_ptr(), None, x.data_ptr(), x.data_ptr(), 4, x.data_ptr(), 0.0, None, None)
+    assert rc == fmx._lib.ERR_SHAPE                                # ld_bi < k

@@ -223,8 +223,10 @@ def test_fused_mlp_kernel_equals_pytorch_path(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["DeepFMAdam", "NFMAdam"])
-def test_deep_trainer_step_vs_oracle(name):
-    """fmx.DeepFMTrainer (device tensors, PyTorch MLP, world size 1) against the oracle's class step under SGD."""
+@pytest.mark.parametrize("native", [True, False])
+def test_deep_trainer_step_vs_oracle(name, native):
+    """fmx.DeepFMTrainer (device tensors, world size 1; MLP section through fmx_mlp_section or through PyTorch autograd)
+    against the oracle's class step under SGD."""
     import fmx
     import torch.nn as nn
     z, meta = load_model_fixture(name, "criteo39s")
@@ -244,7 +246,8 @@ def test_deep_trainer_step_vs_oracle(name):
     hyper = fmx.Hyper(lr=lr)
     loss_kind = orc.LOSS_KIND[(name, "fit")]
     tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, hyper, "sgd"), layers, k, table.kp, mlp_lr=lr,
-                           fm_term=(name == "DeepFMAdam"), loss=loss_kind)
+                           fm_term=(name == "DeepFMAdam"), loss=loss_kind, native_mlp=native)
+    assert tr.native == native
     Xi, Y = z["A/Xi1"], z["A/Y1"]                     # Xv == 1
     idx_d, _, y_d = eng.to_device(Xi.astype(np.int32), None, Y)
     tr.step(idx_d, y_d)
