@@ -1965,15 +1965,16 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     g.N = H;
     g.K = in;
     g.k_chunk = in;
-    g.vecA = vec_ok(g.A, g.lda);
-    g.vecB = vec_ok(g.Bm, g.ldb);
+    g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
+    g.b_bytes = (unsigned)((size_t)H * g.ldb * 4);
+    g.vec = (size_t)B * g.lda * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 0, 1);
     launch_gemm<0, 1, EPI_BIAS_RELU>(g, 1, st);
   }
   // ---- loss, dL/dlogit, dH_L ----
   {
     MlpLossArgs a;
     a.H = w.acts + (size_t)(L - 1) * act;
-    a.dH = w.dHa;
+    a.dH = w.dH + (size_t)(L - 1) * act;
     a.base = base;
     a.y = y;
     a.out = logit_out;
@@ -1987,9 +1988,13 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     hipLaunchKernelGGL(k_mlp_loss, dim3((B + 3) / 4), dim3(256), 0, st, a);
   }
   // ---- backward ----
-  float *cur = w.dHa, *nxt = w.dHb;
+  int splits[MLP_BIG_MAX_L] = {0};
+  WgradBatch wb;
+  wb.n = 0;
+  int wgx = 1;
   for (int l = L - 1; l >= 0; --l) {
     const int in = l == 0 ? k : H;
+    float *cur = w.dH + (size_t)l * act;
     const float *prev = l == 0 ? bi : w.acts + (size_t)(l - 1) * act;
     const int ldprev = l == 0 ? ld_bi : H;
     {  // dW_l | db_l = dH_l^T . [H_{l-1} | 1], split over the batch
@@ -2003,12 +2008,23 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
       g.M = H;
       g.N = in + 1;
       g.K = B;
-      g.k_chunk = 256;
+      // as many splits of the batch as keep the grid within one workgroup per CU (139 KB of LDS each), at most B / 256
+      const int tiles = ((in + 1 + G_BN - 1) / G_BN) * ((H + G_BM - 1) / G_BM);
+      int n_split = 256 / tiles;
+      if (n_split > w.n_split) n_split = w.n_split;
+      if (n_split < 1) n_split = 1;
+      g.k_chunk = ((B + n_split - 1) / n_split + G_BK - 1) / G_BK * G_BK;
+      n_split = (B + g.k_chunk - 1) / g.k_chunk;
+      splits[l] = n_split;
       g.c_split_stride = (long long)H * w.ldp[l];
       g.ones_col = in;
-      g.vecA = vec_ok(g.A, g.lda);
-      g.vecB = vec_ok(g.Bm, g.ldb);
-      launch_gemm<1, 0, EPI_NONE>(g, w.n_split, st);
+      g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
+      g.b_bytes = (unsigned)((size_t)B * g.ldb * 4);
+      g.vec = (size_t)B * (g.lda > g.ldb ? g.lda : g.ldb) * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 1, 0);
+      wb.g[wb.n] = g;                                  // launched together with the other layers' after the dgrad chain
+      wb.z_end[wb.n] = (wb.n ? wb.z_end[wb.n - 1] : 0) + n_split;
+      if ((in + 1 + G_BN - 1) / G_BN > wgx) wgx = (in + 1 + G_BN - 1) / G_BN;
+      ++wb.n;
     }
     GemmArgs g = base_args();
     g.A = cur;
@@ -2019,23 +2035,30 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     g.N = in;
     g.K = H;
     g.k_chunk = H;
-    g.vecA = vec_ok(g.A, g.lda);
-    g.vecB = vec_ok(g.Bm, g.ldb);
+    g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
+    g.b_bytes = (unsigned)((size_t)H * g.ldb * 4);
+    g.vec = (size_t)B * g.lda * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 0, 0);
     if (l > 0) {  // dH_{l-1} = (dH_l . W_l) * (H_{l-1} > 0)
-      g.C = nxt;
+      g.C = w.dH + (size_t)(l - 1) * act;
       g.ldc = H;
       g.mask = prev;
       g.ldmask = H;
       launch_gemm<0, 0, EPI_MASK>(g, 1, st);
-      float *tmp = cur;
-      cur = nxt;
-      nxt = tmp;
     } else {  // dL/dbi through the MLP, padding columns zeroed
       g.C = gbi_out;
       g.ldc = ld_gbi;
       g.zero_cols_to = ld_gbi;
       launch_gemm<0, 0, EPI_NONE>(g, 1, st);
     }
+  }
+  {  // ---- every layer's dW_l | db_l in one launch ----
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)G_LDS_BYTES);
+      raised = true;
+    }
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3(wgx, (H + G_BM - 1) / G_BM, wb.z_end[wb.n - 1]), dim3(256), G_LDS_BYTES, st, wb);
   }
   // ---- partials -> flat gradients (+ optional SGD), mean loss ----
   {
@@ -2053,12 +2076,11 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     a.grads = grads;
     a.params = mlp->params;
     a.lr = lr_apply;
-    a.n_split = w.n_split;
+    for (int l = 0; l < MLP_BIG_MAX_L; ++l) a.n_split[l] = splits[l];
     a.n_layers = L;
     a.loss_b = w.loss_b;
     a.loss_out = loss_out;
     a.B = B;
-    a.inv_b = 1.0f;  // the per-sample losses are summed; the caller's inv_b is already in dz, and the loss is sum * inv_b:
     a.inv_b = inv_b;
     const int bx = (int)((biggest + 255) / 256);
     hipLaunchKernelGGL(k_mlp_reduce, dim3(bx > 256 ? 256 : bx, L), dim3(256), 0, st, a);

@@ -34,11 +34,28 @@ class HipDeepBackend:
     def mlp_section(self, flat, gflat, k, hidden, n_layers, loss, bi, base, y, inv_b, lr_apply):
         return self.e.mlp_section(flat, gflat, k, hidden, n_layers, loss, bi, base, y, bi.shape[0], inv_b, lr_apply)
 
+    def start_sort(self, idx_g):
+        """The occurrence sort only needs the (gathered) indices: it runs on a side stream beside the forward pass and
+        the MLP section."""
+        e = self.e
+        e._ensure(idx_g.shape[0])
+        cur = torch.cuda.current_stream(e.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=e.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            e.sort(idx_g)
+        self._sorted_for = idx_g.data_ptr()
+
     def update(self, idx_g, S_g, dz_g, gbi_g, fm_term, inv_b):
         e = self.e
         GB = idx_g.shape[0]
         e._ensure(GB)
-        e.sort(idx_g)
+        if getattr(self, "_sorted_for", None) == idx_g.data_ptr() and getattr(self, "_side", None) is not None:
+            torch.cuda.current_stream(e.device).wait_stream(self._side)
+        else:
+            e.sort(idx_g)
+        self._sorted_for = None
         e.update(self.hyper, self.rule, GB, None, dz_g, dz_g if fm_term else None, gbi_g, inv_b=inv_b, with_loss=False, S=S_g)
 
 
@@ -132,6 +149,8 @@ class DeepFMTrainer:
         B = idx_local.shape[0]
         inv_b = 1.0 / (B * self.world)
         idx_g = self._gathered("idx", idx_local)
+        if hasattr(self.backend, "start_sort") and idx_g.is_cuda:
+            self.backend.start_sort(idx_g)
         S, bi, sfirst, logit_fm = self.backend.forward(idx_local)
         base_in = logit_fm if self.fm_term else sfirst + self.backend.bias()
         applied = False

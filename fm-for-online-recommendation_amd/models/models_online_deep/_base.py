@@ -273,6 +273,23 @@ class OnlineFMBase(nn.Module):
             e.update(self._hyper, self.update_rule, B, xv_d, dz, dz if self._fm_term_in_forward else None, gbi,
                      with_loss=False)
             return
+        if self.update_rule != "ftrl" and getattr(self, "native_mlp", True):
+            # mini-batch sizes: the MLP section as fp32 MFMA GEMMs (fmx_mlp_section); the hidden layers then take the
+            # closed form of the reference's fresh-Adam first step, p -= lr * g / (|g| + 1e-8) (or plain SGD)
+            if getattr(self, "_mlp_gflat", None) is None:
+                self._mlp_gflat = torch.zeros_like(self._mlp_flat)
+            _, dz, gbi = e.mlp_section(self._mlp_flat, self._mlp_gflat, k, self.neuron_per_hidden_layer,
+                                       self.num_hidden_layers, self._loss_fit, e.bi[:B],
+                                       self._base_logit(B).contiguous(), y_d, B, 1.0 / B)
+            e.update(self._hyper, self.update_rule, B, xv_d, dz, dz if self._fm_term_in_forward else None, gbi,
+                     with_loss=False)
+            g, lr = self._mlp_gflat, float(self.n)
+            with torch.no_grad():
+                if self.update_rule == "sgd":
+                    self._mlp_flat.sub_(g, alpha=lr)
+                else:
+                    self._mlp_flat.sub_(lr * g / (g.abs() + 1e-8))
+            return
         bi = e.bi[:B, :k].detach().clone().requires_grad_(True)
         base = self._base_logit(B).detach().clone().requires_grad_(True)
         for p in self.hidden_layers.parameters():

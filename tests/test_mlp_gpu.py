@@ -43,7 +43,7 @@ def reference(params, k, H, L, loss, bi, base, y, inv_b):
     ls = F.binary_cross_entropy_with_logits(z, y.double().cpu(), reduction="sum") * inv_b
     ls.backward()
     flat = torch.cat([t.grad.reshape(-1) for pair in zip(Ws, bs) for t in pair])
-    return float(ls), base.grad.numpy(), bi.grad.numpy(), flat.numpy(), out.detach().numpy()
+    return float(ls.detach()), base.grad.numpy(), bi.grad.numpy(), flat.numpy(), out.detach().numpy()
 
 
 def close(a, b, what, rel=2e-5):

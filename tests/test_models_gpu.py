@@ -223,6 +223,25 @@ def test_fused_mlp_kernel_equals_pytorch_path(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["DeepFMAdam", "NFMAdam"])
+def test_mfma_mlp_section_equals_pytorch_path_in_fit(name, monkeypatch):
+    """Batches beyond the one-workgroup kernel go through fmx_mlp_section (fp32 MFMA GEMMs) + the closed form of the
+    fresh-Adam step; with native_mlp = False through PyTorch autograd + a literal torch.optim.Adam: same step."""
+    import fmx
+    z, meta = load_model_fixture(name, "criteo39s")
+    B = meta["B2"]
+    Xi, Xv, Y = z["A/Xi2"].tolist(), z["A/Xv2"].tolist(), z["A/Y2"].tolist()
+    monkeypatch.setattr(fmx.FMEngine, "mlp_fits", staticmethod(lambda *a, **k: False))
+    results = []
+    for native in (True, False):
+        m = build(name, meta, B)
+        m.load_state_dict(sub(z, "A/sd0"))
+        m.native_mlp = native
+        m.fit(Xi, Xv, Y)
+        results.append(sd_np(m))
+    assert_state_close(results[0], results[1], sub(z, "A/sd0"), what="fit: mfma section vs pytorch")
+
+
+@pytest.mark.parametrize("name", ["DeepFMAdam", "NFMAdam"])
 @pytest.mark.parametrize("native", [True, False])
 def test_deep_trainer_step_vs_oracle(name, native):
     """fmx.DeepFMTrainer (device tensors, world size 1; MLP section through fmx_mlp_section or through PyTorch autograd)
