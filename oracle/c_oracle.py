@@ -31,6 +31,9 @@ def load():
         _lib.fmo_fm_step.restype = C.c_double
         _lib.fmo_fm_step.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, fp, C.c_int64, C.c_int, ip, fp, fp, C.c_int, C.c_int,
                                      C.POINTER(Hyper), C.c_float, fp, fp]
+        _lib.fmo_fm_step_mt.restype = C.c_double
+        _lib.fmo_fm_step_mt.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, fp, C.c_int64, C.c_int, ip, fp, fp, C.c_int, C.c_int,
+                                        C.POINTER(Hyper), C.c_float, C.c_int]
     return _lib
 
 
@@ -38,8 +41,9 @@ def _f(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def fm_step(state, rows, x, y, loss_kind, rule, hyper, inv_b=None):
-    """Same contract as fm_oracle.flat_fm_step (state arrays are updated in place); returns the mean loss."""
+def fm_step(state, rows, x, y, loss_kind, rule, hyper, inv_b=None, threads=1):
+    """Same contract as fm_oracle.flat_fm_step (state arrays are updated in place); returns the mean loss.
+    threads > 1: the OpenMP form (columns of `rows` must hold disjoint row ids, as field-partitioned global ids do)."""
     lib = load()
     rows = np.ascontiguousarray(rows, dtype=np.int64)
     B, F = rows.shape
@@ -57,8 +61,13 @@ def fm_step(state, rows, x, y, loss_kind, rule, hyper, inv_b=None):
     for a in (P0, P1, P2, P3):
         assert a is None or (a.dtype == np.float32 and a.flags["C_CONTIGUOUS"])
     k = P0.shape[1]
-    loss = lib.fmo_fm_step(RULES[rule], LOSSES[loss_kind], _f(P0), _f(P1), _f(P2), _f(P3), _f(bias), P0.shape[0], k,
-                           rows.ctypes.data_as(C.POINTER(C.c_int64)), _f(x), _f(y), B, F, C.byref(h), inv_b, None, None)
+    assert k <= 256
+    if threads > 1:
+        loss = lib.fmo_fm_step_mt(RULES[rule], LOSSES[loss_kind], _f(P0), _f(P1), _f(P2), _f(P3), _f(bias), P0.shape[0], k,
+                                  rows.ctypes.data_as(C.POINTER(C.c_int64)), _f(x), _f(y), B, F, C.byref(h), inv_b, threads)
+    else:
+        loss = lib.fmo_fm_step(RULES[rule], LOSSES[loss_kind], _f(P0), _f(P1), _f(P2), _f(P3), _f(bias), P0.shape[0], k,
+                               rows.ctypes.data_as(C.POINTER(C.c_int64)), _f(x), _f(y), B, F, C.byref(h), inv_b, None, None)
     if rule == "ftrl":
         state["zb"], state["nb"] = np.float32(bias[0]), np.float32(bias[1])
     else:

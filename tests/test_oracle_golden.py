@@ -190,3 +190,34 @@ def test_c_oracle_matches_numpy_oracle(rule, loss):
             assert (np.abs(ref - got) > 1e-6).mean() < 2e-3
         else:
             np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6 * max(np.abs(ref).max(), 1e-3))
+
+
+@pytest.mark.parametrize("rule", ["signadam", "sgd", "ftrl"])
+def test_c_oracle_openmp_form_gives_the_same_bits(rule):
+    """fmo_fm_step_mt (bench.py's multi-core cpu_baseline) == fmo_fm_step, bit for bit, over a few steps."""
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/_build/liboracle.so not built (make -C oracle)")
+    rng = np.random.default_rng(3)
+    sizes = [3, 9, 1000, 5000, 4, 17, 200]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    R, k, B = int(offs[-1]), 8, 500
+    V = (rng.normal(size=(R, k)) * 0.3).astype(np.float32)
+    w = (rng.normal(size=R) * 0.3).astype(np.float32)
+    hyp = dict(lr=0.01, eps=1e-8, alpha=0.05, beta=1.0, l1=0.001, l2=0.01)
+    fh = {kk: hyp[kk] for kk in ("alpha", "beta", "l1", "l2")}
+    if rule == "ftrl":
+        mk = lambda: dict(zV=orc.ftrl_z_for_weight(V, **fh), nV=np.full_like(V, 0.2), zw=orc.ftrl_z_for_weight(w, **fh),
+                          nw=np.full_like(w, 0.2), zb=np.float32(0.1), nb=np.float32(0.3))
+    else:
+        mk = lambda: dict(V=V.copy(), w=w.copy(), bias=np.float32(0.37))
+    a, b = mk(), mk()
+    for step in range(3):
+        rows = np.stack([rng.integers(0, s, size=B) for s in sizes], axis=1) + offs[:-1][None, :]
+        x = rng.uniform(-1, 1, size=rows.shape).astype(np.float32)
+        y = (rng.uniform(size=B) < 0.3).astype(np.float32)
+        la = c_oracle.fm_step(a, rows, x, y, "logits", rule, hyp)
+        lb = c_oracle.fm_step(b, rows, x, y, "logits", rule, hyp, threads=4)
+        assert la == lb
+    for kk in a:
+        np.testing.assert_array_equal(np.asarray(a[kk]), np.asarray(b[kk]))
