@@ -1946,7 +1946,6 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     g.mask = nullptr;
     g.ldmask = 0;
     g.c_split_stride = 0;
-    g.ones_col = -1;
     g.zero_cols_to = 0;
     return g;
   };
@@ -2006,10 +2005,10 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
       g.C = w.parts[l];
       g.ldc = w.ldp[l];
       g.M = H;
-      g.N = in + 1;
+      g.N = in;
       g.K = B;
       // as many splits of the batch as keep the grid within one workgroup per CU (139 KB of LDS each), at most B / 256
-      const int tiles = ((in + 1 + G_BN - 1) / G_BN) * ((H + G_BM - 1) / G_BM);
+      const int tiles = ((in + G_BN - 1) / G_BN) * ((H + G_BM - 1) / G_BM);
       int n_split = 256 / tiles;
       if (n_split > w.n_split) n_split = w.n_split;
       if (n_split < 1) n_split = 1;
@@ -2017,13 +2016,13 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
       n_split = (B + g.k_chunk - 1) / g.k_chunk;
       splits[l] = n_split;
       g.c_split_stride = (long long)H * w.ldp[l];
-      g.ones_col = in;
       g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
       g.b_bytes = (unsigned)((size_t)B * g.ldb * 4);
       g.vec = (size_t)B * (g.lda > g.ldb ? g.lda : g.ldb) * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 1, 0);
       wb.g[wb.n] = g;                                  // launched together with the other layers' after the dgrad chain
       wb.z_end[wb.n] = (wb.n ? wb.z_end[wb.n - 1] : 0) + n_split;
-      if ((in + 1 + G_BN - 1) / G_BN > wgx) wgx = (in + 1 + G_BN - 1) / G_BN;
+      wb.bias_col[wb.n] = in;
+      if ((in + G_BN - 1) / G_BN > wgx) wgx = (in + G_BN - 1) / G_BN;
       ++wb.n;
     }
     GemmArgs g = base_args();
@@ -2058,7 +2057,8 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
                                 (int)G_LDS_BYTES);
       raised = true;
     }
-    hipLaunchKernelGGL(k_mlp_wgrad, dim3(wgx, (H + G_BM - 1) / G_BM, wb.z_end[wb.n - 1]), dim3(256), G_LDS_BYTES, st, wb);
+    // grid x = the GEMM's column tiles + one slice for the bias columns (y there = blocks of 256 columns of dH_l)
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3(wgx + 1, (H + G_BM - 1) / G_BM, wb.z_end[wb.n - 1]), dim3(256), G_LDS_BYTES, st, wb);
   }
   // ---- partials -> flat gradients (+ optional SGD), mean loss ----
   {
