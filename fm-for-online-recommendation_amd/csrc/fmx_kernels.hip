@@ -803,8 +803,38 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
     accw = 0.f;
   }
 
+  // ---- the tile's hand-off state is known before any row is touched: does the run that came in end here (this tile
+  //      CLOSES it), does the tile lie inside one run (THROUGH), does its last run go on (trail)?  The sum of that last
+  //      run so far is the last group's carry-out.  With the in-launch hand-off (INL) the record and the flag word
+  //      (launch sequence << 4 | lead_state << 2 | trail_state) are published NOW, before the row updates of pass 2, so
+  //      that closing tiles further on never wait for this tile's FTRL arithmetic and store acknowledgements: records
+  //      write-through, s_waitcnt vmcnt(0), then the flag as an agent-scope atomic; records and flags sc1 on both sides.
+  bool closes_here = false;
+#pragma unroll
+  for (int j = 0; j < EPG; ++j) closes_here = closes_here || (tail[j] && k[j] == tile_prevkey);
+  int lead_state = __ballot(closes_here) != 0ull ? LEAD_CLOSES : LEAD_NONE;
+  int trail_state = 0;
+  const bool tile_open = __shfl((int)trail_open, WAVE - 1) != 0;
+  if (tile_open) {
+    const bool through = __shfl((int)(k[EPG - 1] == tile_prevkey), WAVE - 1) != 0;
+    if (through) lead_state = LEAD_THROUGH;  // the whole tile is one run, open at both ends
+    else trail_state = 1;
+    if (slot == SLOTS - 1) {
+      if (INL) store_part_sc1(part + (through ? 0 : REC), q, kp, tV, tA.vec(), tw);
+      else store_part(part + (through ? 0 : REC), q, kp, tV, tA.vec(), tw);
+    }
+  }
+  if (INL) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_store(a.meta + (size_t)gt * 2, (int32_t)((a.seq << 4) | ((uint32_t)lead_state << 2) | (uint32_t)trail_state),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (lane == 0) {
+    a.meta[(size_t)gt * 2] = lead_state;
+    a.meta[(size_t)gt * 2 + 1] = trail_state;
+  }
+
   // ---- pass 2: walk the occurrences again; at the tail of a run apply the update or leave a partial ----
-  bool closes = false;
 #pragma unroll
   for (int j = 0; j < EPG; ++j) {
     if (j > 0 && k[j] != k[j - 1]) {
@@ -821,42 +851,18 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
         const RowRegs r = PREFETCH_ROWS ? row[PREFETCH_ROWS ? j : 0] : load_row<LAYOUT>(rp, q, kp, a.zoff);
         update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, accV, accA.vec(), accw, a.h);
       } else {
-        // the run that came in from the previous tile ends here
+        // the run that came in from the previous tile ends here: its part inside this tile (read back by this wave's
+        // combine below, or by k_fm_fixup)
         if (INL) store_part_sc1(part, q, kp, accV, accA.vec(), accw);
         else store_part(part, q, kp, accV, accA.vec(), accw);
-        closes = true;
       }
     }
   }
-  // ---- the tile's last run continues in the next tile: its sum so far is the last group's carry-out ----
-  int lead_state = __ballot(closes) != 0ull ? LEAD_CLOSES : LEAD_NONE;
-  int trail_state = 0;
-  const bool tile_open = __shfl((int)trail_open, WAVE - 1) != 0;
-  if (tile_open) {
-    const bool through = __shfl((int)(k[EPG - 1] == tile_prevkey), WAVE - 1) != 0;
-    if (through) lead_state = LEAD_THROUGH;  // the whole tile is one run, open at both ends
-    else trail_state = 1;
-    if (slot == SLOTS - 1) {
-      if (INL) store_part_sc1(part + (through ? 0 : REC), q, kp, tV, tA.vec(), tw);
-      else store_part(part + (through ? 0 : REC), q, kp, tV, tA.vec(), tw);
-    }
-  }
-  if (!INL) {
-    if (lane == 0) {
-      a.meta[(size_t)gt * 2] = lead_state;
-      a.meta[(size_t)gt * 2 + 1] = trail_state;
-    }
-    return;
-  }
-  // ---- in-launch hand-off (INL): publish this tile's records, then the CLOSING tile of a run sums the records of the
-  //      tiles before it (they were dispatched earlier and wait on nothing) and applies the row update -- no second
-  //      launch.  Flag word = (launch sequence << 4) | lead_state << 2 | trail_state, stored after the records are
-  //      acknowledged (vmcnt(0)); records and flags are sc1 on both sides. ----
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0)
-    __hip_atomic_store(a.meta + (size_t)gt * 2, (int32_t)((a.seq << 4) | ((uint32_t)lead_state << 2) | (uint32_t)trail_state),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!INL) return;
+  // ---- in-launch hand-off (INL): the CLOSING tile of a run sums the records of the tiles before it (they were
+  //      dispatched earlier and wait on nothing) and applies the row update -- no second launch ----
   if (lead_state != LEAD_CLOSES) return;  // wave-uniform
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own lead record (read back below) is acknowledged
   const int t = gt - f * tiles_per_field;
   float *rp = a.rows + (row0 + tile_prevkey) * (size_t)a.stride;
   RowRegs r;
