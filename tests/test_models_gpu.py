@@ -284,3 +284,38 @@ def test_deep_trainer_step_vs_oracle(name, native):
         got[f"hidden_layers.{j}.bias"] = layer.bias.detach().cpu().numpy()
     ref = {kk: v for kk, v in ref.items() if kk in got}
     assert_state_close(got, ref, {kk: sd0[kk] for kk in ref}, what=f"{name} sgd step")
+
+
+def test_config4_nfm_hedge_on_a_frappe_shaped_10m_row_table():
+    """BASELINE.json configs[4] as a parity case: online NFM + Hedge backprop (reference nfm_onn.py:111-156) on
+    Frappe-shaped input -- 10 one-hot fields over 10 M embedding rows, k = 16, L = 3 -- in the reference's online protocol
+    (predict, then fit, one sample at a time) against the oracle started from the same parameters.  The tables are not
+    trained by Hedge (the reference's behaviour), so parity is on predictions, alpha and the hidden layers."""
+    from models.models_online_deep.nfm_onn import NFMOnn
+    torch.manual_seed(4)
+    sizes = [1_000_000] * 10
+    k, L, H, n_samples = 16, 3, 32, 120
+    m = NFMOnn(sizes, embedding_size=k, num_hidden_layers=L, neuron_per_hidden_layer=H, batch_size=1, n=0.01)
+    sd0 = sd_np(m)
+    rng = np.random.default_rng(5)
+    Xi = np.stack([np.minimum(rng.zipf(1.2, size=n_samples) - 1, s - 1) for s in sizes], axis=1)   # skewed ids, heavy head
+    Xi[::7] = np.stack([rng.integers(0, s, size=len(Xi[::7])) for s in sizes], axis=1)               # and the long tail
+    Xv = np.ones_like(Xi, dtype=np.float32)
+    Y = (rng.uniform(size=n_samples) < 0.4).astype(np.float32)
+    om = orc.OracleModel("NFMOnn", {kk: v.copy() for kk, v in sd0.items()}, batch_size=1)
+    preds_h, preds_o = [], []
+    for i in range(n_samples):
+        xi, xv = Xi[i].reshape(1, -1, 1).tolist(), Xv[i].reshape(1, -1).tolist()
+        preds_h.append(bool(np.asarray(m.predict(xi, xv)).reshape(-1)[0]))
+        preds_o.append(bool(np.asarray(om.predict(Xi[i], Xv[i])).reshape(-1)[0]))
+        m.fit(xi, xv, [float(Y[i])])
+        om.fit([Xi[i]], [Xv[i]], [Y[i]])
+    assert preds_h == preds_o
+    got, ref = sd_np(m), om.state_dict()
+    assert_close(got["alpha"], ref["alpha"], 1e-4, 1e-6, "alpha")
+    for j in range(L):
+        for part in ("weight", "bias"):
+            key = f"hidden_layers.{j}.{part}"
+            assert_close(got[key], ref[key], 1e-4, 1e-6 * np.abs(ref[key]).max(), key)
+    for i in (0, 9):        # Hedge leaves the tables alone
+        np.testing.assert_array_equal(got[f"second_order_embeddings.{i}.weight"], sd0[f"second_order_embeddings.{i}.weight"])
