@@ -319,3 +319,25 @@ def test_config4_nfm_hedge_on_a_frappe_shaped_10m_row_table():
             assert_close(got[key], ref[key], 1e-4, 1e-6 * np.abs(ref[key]).max(), key)
     for i in (0, 9):        # Hedge leaves the tables alone
         np.testing.assert_array_equal(got[f"second_order_embeddings.{i}.weight"], sd0[f"second_order_embeddings.{i}.weight"])
+
+
+def test_driver_script_flow_end_to_end(tmp_path, capsys):
+    """The reference's driver (main_experiment.py:60-162) on synthetic Criteo-shaped CSVs in its own file format: reading,
+    batch schedule, pre-training through update_embedding, the online run_experiment loop over the five classes, the
+    result pickle and the model pickles.  Small sizes; checks the flow and the artefacts, not accuracy."""
+    import _experiment
+    res = _experiment.run("Iteration", argv=["--synthetic", "--num-batchdata", "48", "--num-batch", "4", "--pretrain-iters", "3",
+                                              "--out", str(tmp_path) + "/"])
+    names = ["DeepFMAdam", "DeepFMOnn", "NFMAdam", "NFMOnn", "FMAdam"]
+    assert sorted(res["accuracy"].keys()) == sorted(names)
+    for nme in names:
+        assert len(res["accuracy"][nme]) == 4 and all(0.0 <= a <= 100.0 for a in res["accuracy"][nme])
+        assert all(set(r.keys()) == {"tpr", "fpr"} for r in res["roc"][nme])
+    out = capsys.readouterr().out
+    assert "i th iter 0 , loss :" in out and "confusion matrix :" in out
+    models = sorted(p.name for p in (tmp_path / "save_model").iterdir())
+    assert models == sorted(f"{nme}_Iteration.pickle" for nme in names)
+    with open(tmp_path / "save_model" / "FMAdam_Iteration.pickle", "rb") as f:
+        m = pickle.load(f)                                # our own file, written a moment ago
+    assert str(m).startswith("FMAdam-")
+    assert len(list((tmp_path / "save_log").iterdir())) == 1
