@@ -235,26 +235,37 @@ def main():
         eng.check_error_flag()
         losses = loss_buf[:args.steps].cpu().numpy()
         assert np.isfinite(losses).all(), "non-finite loss in the timed region"
+        # spread of the step time: 20 separately timed chunks of 100 steps (each chunk pays one pipeline start)
+        chunk_us = []
+        for _ in range(20):
+            barrier()
+            tc = time.perf_counter()
+            eng.stream(hyper, RULE, "logits", idx_pool, y_pool, 100, loss_buf)
+            barrier()
+            chunk_us.append((time.perf_counter() - tc) / 100 * 1e6)
         # the measuring pass (fmx.h, fmx_fm_stream with kernel_ms): per step every kernel is launched 8x back to back
         # between two HIP events on the launch stream, an empty event pair's own cost subtracted: per-launch durations
         # for the roofline.  Not the pass timed above.
         barrier()
-        t1 = time.perf_counter()
-        kernel_ms = eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.steps, loss_buf, timed=True)
+        kernel_ms = eng.stream(hyper, RULE, "logits", idx_pool, y_pool, min(args.steps, 300), loss_buf, timed=True)
         barrier()
-        dt_events = time.perf_counter() - t1
     else:
         # ---- N GPUs: exact data parallelism (fmx.DataParallelFM): forward on the local slice, all-gather of the
         #      low-rank factors (idx, S, dlogit) over RCCL, identical row-reduced update of the replicas ----
         dp = fmx.DataParallelFM(fmx.HipBackend(eng, hyper, RULE, "logits"))
 
         def run(n, first=0):
+            # the index all-gather and the global sort of later steps run ahead on prefetch streams: two steps ahead when
+            # a step is one exact update, one step (= its sub-steps) ahead when the global batch is split
+            depth = 2 if dp._sub_steps(BATCH) == 1 else 1
             out = None
+            for d in range(min(depth, n)):
+                dp.prefetch(idx_pool[(first + d) % N_POOL])
             for s in range(n):
+                if s + depth < n:
+                    dp.prefetch(idx_pool[(first + s + depth) % N_POOL])
                 j = (first + s) % N_POOL
                 out = dp.step(idx_pool[j], y_pool[j])
-                if s + 1 < n:
-                    dp.prefetch(idx_pool[(first + s + 1) % N_POOL])   # next step's index gather + sort, off its critical path
             return out
         work = torch.cuda.Stream(device=dev)          # not the legacy default stream (slow to enqueue on)
         with torch.cuda.stream(work):
@@ -267,7 +278,6 @@ def main():
         eng.check_error_flag()
         losses = last.cpu().numpy()
         assert np.isfinite(losses).all(), "non-finite loss in the timed region"
-        dt_events = float("nan")
         tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
@@ -322,7 +332,8 @@ def main():
         "final_loss": float(losses[-1]),
     }
     if kernel_ms is not None:
-        sort_ms, fwd_ms, upd_ms, pair_ms = [v / args.steps for v in kernel_ms]
+        sort_ms, fwd_ms, upd_ms, pair_ms = [v / min(args.steps, 300) for v in kernel_ms]
+        out["step_us_over_100_step_chunks"] = {q: float(np.percentile(chunk_us, p)) for q, p in (("p10", 10), ("p50", 50), ("p90", 90))}
         ach = BYTES_K_UPDATE * BATCH / (upd_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_fm_update", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
@@ -332,7 +343,6 @@ def main():
                                        "profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same command"}
         out["kernels_ms_per_launch"] = {"k_sort_occ": sort_ms, "k_fm_forward": fwd_ms, "k_fm_update": upd_ms,
                                         "empty_event_pair": pair_ms}
-        out["ms_per_step_event_pass"] = dt_events / args.steps * 1e3
     else:
         out["roofline"] = {"bound": "hbm", "kernel": "k_fm_update", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": None, "traffic": traffic, "measured": "per-kernel events are taken at N=1 only"}

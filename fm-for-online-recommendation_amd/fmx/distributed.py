@@ -43,30 +43,36 @@ class HipBackend:
         self.e.forward(self.hyper, idx, None, y, loss=self.loss, inv_b=inv_b, want_first=False, want_bi=False, records=rec)
         return rec
 
-    def start_sort(self, idx_g):
-        """The global occurrence sort only needs the gathered indices: it runs on a side stream while this rank's
-        forward pass and the S / dlogit gathers proceed."""
+    N_SLOTS = 4   # batches that may be gathered + sorted ahead of their update, each with a workspace of its own
+
+    def _slot_ws(self, slot, GB):
+        if not hasattr(self, "_ws"):
+            self._ws = {}
+        ws = self._ws.get(slot)
+        need = int(self.e.lib.fmx_workspace_bytes(self.e.table.c_struct(), GB)) // 4
+        if ws is None or ws.numel() < need:
+            ws = self._ws[slot] = self.e.new_workspace(GB)
+        return ws
+
+    def start_sort(self, idx_g, slot=0):
+        """The global occurrence sort only needs the gathered indices; it is launched on the CURRENT stream (the caller
+        runs it on a prefetch stream) into the slot's own workspace."""
         e = self.e
         e._ensure(idx_g.shape[0])
-        cur = torch.cuda.current_stream(e.device)
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=e.device)
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
-            e.sort(idx_g)
-        self._sorted_for = idx_g.data_ptr()
+        e.sort(idx_g, workspace=self._slot_ws(slot, idx_g.shape[0]))
 
-    def update(self, idx_g, rec_g, inv_b):
-        """Row-reduced update over the global batch (sorted by start_sort, or here); returns the mean-loss tensor [1]."""
+    def update(self, idx_g, rec_g, inv_b, slot=None):
+        """Row-reduced update over the global batch (sorted into `slot` by start_sort, or here); returns the mean-loss
+        tensor [1]."""
         e = self.e
         GB = idx_g.shape[0]
         e._ensure(GB)
-        if getattr(self, "_sorted_for", None) == idx_g.data_ptr() and getattr(self, "_side", None) is not None:
-            torch.cuda.current_stream(e.device).wait_stream(self._side)
-        else:
+        if slot is None:                                      # nothing prepared: sort here, in the engine's own workspace
             e.sort(idx_g)
-        self._sorted_for = None
-        e.update(self.hyper, self.rule, GB, None, None, inv_b=inv_b, with_loss=True, records=rec_g)
+            ws = None
+        else:
+            ws = self._slot_ws(slot, GB)
+        e.update(self.hyper, self.rule, GB, None, None, inv_b=inv_b, with_loss=True, records=rec_g, workspace=ws)
         return e.loss_out
 
 
@@ -104,10 +110,7 @@ class DataParallelFM:
         whose largest field needs 18 index bits), the batch is processed as consecutive exact steps over equal slices of
         every rank's samples -- still exact online learning, with a smaller global batch per update."""
         B = idx_local.shape[0]
-        cap = getattr(self.backend, "max_global_batch", None)
-        n_sub = 1
-        while cap is not None and (B // n_sub) * self.world > cap and (B // n_sub) % 2 == 0:
-            n_sub *= 2
+        n_sub = self._sub_steps(B)
         if n_sub > 1:
             out = None
             Bs = B // n_sub
@@ -116,27 +119,60 @@ class DataParallelFM:
             return out
         return self._step(idx_local, y_local)
 
-    def prefetch(self, idx_next):
-        """Gather (and start sorting) the NEXT step's indices now: they do not depend on the weights, and it takes the
-        index all-gather off the next step's critical path.  Two alternating buffers, so a prefetch issued while a step
-        still reads its own gathered indices does not overwrite them."""
-        self._pf_toggle = 1 - getattr(self, "_pf_toggle", 0)
-        idx_g = self._gathered(f"idx_pf{self._pf_toggle}", idx_next)
-        self._pref = (idx_next.data_ptr(), idx_g)
+    def _sub_steps(self, B):
         cap = getattr(self.backend, "max_global_batch", None)
-        if hasattr(self.backend, "start_sort") and (cap is None or idx_g.shape[0] <= cap):
-            self.backend.start_sort(idx_g)
+        n_sub = 1
+        while cap is not None and (B // n_sub) * self.world > cap and (B // n_sub) % 2 == 0:
+            n_sub *= 2
+        return n_sub
+
+    def prefetch(self, idx_next):
+        """Gather and sort a LATER step's indices now (they do not depend on the weights): the index all-gather and the
+        global occurrence sort of every sub-step run on a prefetch stream of their own, into a slot (gathered-index
+        buffer + workspace) of their own, beside the steps in front of them.  Call it before the step it should overlap
+        with; up to backend.N_SLOTS sub-steps may be in flight (slots are reused in order)."""
+        if not (idx_next.is_cuda and hasattr(self.backend, "start_sort")):
+            return
+        if not hasattr(self, "_pref"):
+            self._pref, self._next_slot, self._slot_free, self._pf_streams = {}, 0, {}, {}
+        B = idx_next.shape[0]
+        n_sub = self._sub_steps(B)
+        Bs = B // n_sub
+        n_slots = getattr(self.backend, "N_SLOTS", 1)
+        if len(self._pref) + n_sub > n_slots:
+            return                                            # no free slot: the step will gather and sort by itself
+        dev = idx_next.device
+        for j in range(n_sub):
+            part = idx_next[j * Bs:(j + 1) * Bs]
+            slot = self._next_slot
+            self._next_slot = (slot + 1) % n_slots
+            pf = self._pf_streams.get(slot)
+            if pf is None:
+                pf = self._pf_streams[slot] = torch.cuda.Stream(device=dev)
+            pf.wait_stream(torch.cuda.current_stream(dev)) if slot not in self._slot_free else pf.wait_event(self._slot_free[slot])
+            with torch.cuda.stream(pf):
+                idx_g = self._gathered(f"idx_slot{slot}", part)
+                self.backend.start_sort(idx_g, slot)
+                ready = torch.cuda.Event()
+                ready.record(pf)
+            self._pref[part.data_ptr()] = (idx_g, slot, ready)
 
     def _step(self, idx_local, y_local):
         B = idx_local.shape[0]
         inv_b = 1.0 / (B * self.world)
-        pref, self._pref = getattr(self, "_pref", None), None
-        if pref is not None and pref[0] == idx_local.data_ptr() and pref[1].shape[0] == B * self.world:
-            idx_g = pref[1]                                   # gathered (and being sorted) since the previous step
-        else:
-            idx_g = self._gathered("idx", idx_local)          # independent of the weights: issued first
-            if hasattr(self.backend, "start_sort"):
-                self.backend.start_sort(idx_g)
+        pref = getattr(self, "_pref", {}).pop(idx_local.data_ptr(), None) if idx_local.is_cuda else None
+        if pref is not None and pref[0].shape[0] != B * self.world:
+            pref = None
         rec = self.backend.forward(idx_local, y_local, inv_b)
         rec_g = self._gathered("rec", rec)
-        return self.backend.update(idx_g, rec_g, inv_b)
+        if pref is None:                                      # nothing prepared: gather and sort in line
+            idx_g = self._gathered("idx", idx_local)
+            return self.backend.update(idx_g, rec_g, inv_b)
+        idx_g, slot, ready = pref
+        cur = torch.cuda.current_stream(idx_local.device)
+        cur.wait_event(ready)
+        out = self.backend.update(idx_g, rec_g, inv_b, slot)
+        free = torch.cuda.Event()
+        free.record(cur)
+        self._slot_free[slot] = free                          # the slot's buffers may be overwritten after this update
+        return out

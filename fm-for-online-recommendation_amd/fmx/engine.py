@@ -111,14 +111,21 @@ class FMEngine:
                                            _lib.LOSSES[loss], inv_b, C.byref(out), self._stream()))
         return B
 
-    def sort(self, idx_d):
+    def new_workspace(self, B):
+        """A further (zero-filled) per-step workspace for batches up to B: a caller that sorts several batches ahead keeps
+        one per batch in flight and passes it to sort() / update()."""
+        nbytes = int(self.lib.fmx_workspace_bytes(self.table.c_struct(), B))
+        return torch.zeros(nbytes // 4, dtype=torch.int32, device=self.device)
+
+    def sort(self, idx_d, workspace=None):
         B = idx_d.shape[0]
         self._ensure(B)
-        _lib.check(self.lib.fmx_sort_occurrences(self.table.c_struct(), idx_d.data_ptr(), B, self.workspace.data_ptr(),
+        ws = self.workspace if workspace is None else workspace
+        _lib.check(self.lib.fmx_sort_occurrences(self.table.c_struct(), idx_d.data_ptr(), B, ws.data_ptr(),
                                                  self.error.data_ptr(), self._stream()))
 
     def update(self, hyper, rule, B, xv_d, dz_first, dz_bi=None, gbi=None, inv_b=None, with_loss=True, S=None, loss_b=None,
-               records=None, fm_term=True):
+               records=None, fm_term=True, workspace=None):
         """Row-reduced backward + fused update for the batch whose occurrences self.sort() just listed.
         S / loss_b default to the buffers the last forward() filled (a data-parallel caller passes gathered ones, or
         `records` [B, ld] as written by forward(records=...): then dz_first = dz_bi = the records' dz field)."""
@@ -133,7 +140,8 @@ class FMEngine:
             S = self.S if S is None else S
             loss_b = self.loss_b if loss_b is None else loss_b
             S_p, dzf_p, dzb_p, loss_p = S.data_ptr(), dz_first.data_ptr(), _ptr(dz_bi), loss_b.data_ptr()
-        _lib.check(self.lib.fmx_fm_update(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], self.workspace.data_ptr(),
+        ws = self.workspace if workspace is None else workspace
+        _lib.check(self.lib.fmx_fm_update(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], ws.data_ptr(),
                                           _ptr(xv_d), S_p, dzf_p, dzb_p, _ptr(gbi), B, ld,
                                           loss_p if with_loss else None, inv_b,
                                           self.loss_out.data_ptr() if with_loss else None, self._stream()))

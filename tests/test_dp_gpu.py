@@ -83,3 +83,47 @@ def test_two_ranks_bit_identical_to_one_process():
         assert losses == ref_losses
         np.testing.assert_array_equal(rows, ref_rows)
         np.testing.assert_array_equal(bias, ref_bias)
+
+
+@pytest.mark.parametrize("cap,depth", [(None, 2), (192, 1)])
+def test_prefetch_slots_and_sub_steps_equal_plain_steps(cap, depth):
+    """DataParallelFM with indices gathered + sorted ahead on prefetch streams (slots with a workspace each), with and
+    without the split of a step into sub-steps, leaves the same bits as the same steps with nothing prepared ahead."""
+    import fmx
+    hyp = fmx.Hyper(**HYP)
+    batches = _batches(2)                                       # global batches of 768
+    # reference: the same steps with nothing prepared ahead (every step gathers and sorts for itself, in line)
+    n_sub = 1 if cap is None else 4
+    t_ref = _table(fmx)
+    e_ref = fmx.FMEngine(t_ref, max_batch=B_LOCAL * 2)
+    be_ref = fmx.HipBackend(e_ref, hyp, "ftrl", "logits")
+    if cap is not None:
+        be_ref.max_global_batch = cap
+    dp_ref = fmx.DataParallelFM(be_ref)
+    ref_losses = []
+    for idx, y in batches:
+        idx_d, _, y_d = e_ref.to_device(idx, None, y)
+        ref_losses.append(float(dp_ref.step(idx_d, y_d)[0]))
+    t = _table(fmx)
+    eng = fmx.FMEngine(t, max_batch=B_LOCAL * 2)
+    be = fmx.HipBackend(eng, hyp, "ftrl", "logits")
+    if cap is not None:
+        be.max_global_batch = cap
+    dp = fmx.DataParallelFM(be)
+    assert dp._sub_steps(B_LOCAL * 2) == n_sub
+    data = [eng.to_device(idx, None, y) for idx, y in batches]
+    losses = []
+    work = torch.cuda.Stream()
+    with torch.cuda.stream(work):
+        for d in range(depth):
+            dp.prefetch(data[d][0])
+        for i, (idx_d, _, y_d) in enumerate(data):
+            if i + depth < len(data):
+                dp.prefetch(data[i + depth][0])
+            losses.append(dp.step(idx_d, y_d).clone())
+    torch.cuda.synchronize()
+    eng.check_error_flag()
+    assert not dp._pref, "every prefetched batch must have been consumed"
+    assert [float(l[0]) for l in losses] == ref_losses
+    np.testing.assert_array_equal(t.rows.cpu().numpy(), t_ref.rows.cpu().numpy())
+    np.testing.assert_array_equal(t.bias.cpu().numpy(), t_ref.bias.cpu().numpy())
