@@ -123,7 +123,6 @@ __device__ __forceinline__ float bcewl(float z, float y) {
 // k_sort_occ
 // ------------------------------------------------------------------------------------------------------------
 struct SortArgs {
-  int32_t debug;  // timing experiments only (FMX_SORT_DEBUG): 1 = skip the in-wave sort, 2 = skip the merge rounds, 3 = both
   // one launch may sort several batches of a pool: workgroup (f, j) sorts field f of batch (pool_first + j) % n_pool into
   // sorted + j * sorted_stride (n_batches == 1 and pool_stride == 0 for a single batch)
   int32_t n_pool, pool_first, n_batches;
@@ -209,13 +208,11 @@ __device__ __forceinline__ void bitonic_local(uint32_t (&v)[E], int tid, int k, 
   }
 }
 
-// Device body of the occurrence sort of ONE field (the calling workgroup: nt threads, nt * E == Bp).
-//   MERGE = true   every wave bitonic-sorts its 64 E composites in registers (no LDS, no barrier), then log2(nt / 64)
-//                  rounds of pairwise merging: every element finds its rank in the partner run by binary search in LDS
-//                  (composites are unique, so the merge is exact and stable).  Needs 2 * Bp words of LDS.
-//   MERGE = false  the full bitonic network with its cross-wave stages through LDS (Bp words): 78 dependent stages at
-//                  Bp = 4096 against 36 + 4 rounds above; kept for Bp > 16384 where two LDS buffers do not fit.
-template <int E, bool MERGE>
+// Device body of the occurrence sort of ONE field (the calling workgroup: nt threads, nt * E == Bp): the full bitonic
+// network, stages with partner distance < 64 E in registers / DPP, the cross-wave stages through LDS (Bp words); 78
+// dependent stages at Bp = 4096.  (Tried and removed: every wave sorting its 64 E composites in registers followed by
+// binary-search merge rounds in LDS -- 36 stages + 4 rounds, but LDS-bandwidth bound: 31 us against 22.)
+template <int E>
 __device__ __forceinline__ void sort_field(const SortArgs &a, int f, uint32_t *sm) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const uint32_t vocab = (uint32_t)(a.foff[f + 1] - a.foff[f]);
@@ -233,69 +230,6 @@ __device__ __forceinline__ void sort_field(const SortArgs &a, int f, uint32_t *s
   }
   const int wave_span = 64 * E;  // elements held by one wave
   uint32_t *dst = a.sorted + (size_t)f * a.Bp;
-  if (MERGE) {
-    const int kmax = a.Bp < wave_span ? a.Bp : wave_span;
-    if (!(a.debug & 1))
-      for (int k = 2; k <= kmax; k <<= 1) bitonic_local<E>(v, tid, k, k >> 1);  // ascending runs of 64 E (i & k == 0 below 2 * span)
-    // NOTE: with the blocked layout wave w holds elements [w * span, (w + 1) * span): bit `span` of i alternates per wave,
-    // so odd waves come out DESCENDING from the bitonic levels above; the merge below reads them reversed.
-    if (a.Bp <= wave_span) {
-#pragma unroll
-      for (int r = 0; r < E; ++r) dst[tid * E + r] = v[r];
-      return;
-    }
-    uint32_t *cur = sm, *nxt = sm + a.Bp;
-    const int wave = tid >> 6;
-    {
-      // store the wave's run ascending: odd waves reverse their positions
-      const int base = wave * wave_span;
-      const bool desc = (wave & 1) != 0;
-#pragma unroll
-      for (int r = 0; r < E; ++r) {
-        const int pos = (tid & 63) * E + r;
-        cur[base + (desc ? wave_span - 1 - pos : pos)] = v[r];
-      }
-    }
-    __syncthreads();
-    for (int L = wave_span; L < a.Bp && !(a.debug & 2); L <<= 1) {  // merge runs of length L pairwise
-      uint32_t x[E];
-      const uint32_t *other[E];
-      int rank[E], dest0[E];
-      bool in_b[E];
-#pragma unroll
-      for (int r = 0; r < E; ++r) {
-        const int i = tid + r * nt;            // element handled by this thread in this round
-        const int pair = i / (2 * L);
-        const int off = i - pair * 2 * L;      // position inside the pair of runs
-        in_b[r] = off >= L;
-        x[r] = cur[i];
-        other[r] = cur + pair * 2 * L + (in_b[r] ? 0 : L);
-        dest0[r] = pair * 2 * L + (in_b[r] ? off - L : off);
-        rank[r] = 0;
-      }
-      // branch-free binary search, the E searches interleaved: rank = elements of the partner run that are < x for the
-      // left run, <= x for the right run (a stable merge; real composites are unique, the 0xFFFFFFFF padding is not)
-      for (int w = L >> 1; w >= 1; w >>= 1) {
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-          const uint32_t o = other[r][rank[r] + w - 1];
-          rank[r] += (in_b[r] ? o <= x[r] : o < x[r]) ? w : 0;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < E; ++r) {
-        const uint32_t o = other[r][rank[r]];
-        rank[r] += (in_b[r] ? o <= x[r] : o < x[r]) ? 1 : 0;
-        nxt[dest0[r] + rank[r]] = x[r];
-      }
-      __syncthreads();
-      uint32_t *t = cur;
-      cur = nxt;
-      nxt = t;
-    }
-    for (int i = tid; i < a.Bp; i += nt) dst[i] = cur[i];
-    return;
-  }
   const int half = a.Bp >> 1;
   for (int k = 2; k <= a.Bp; k <<= 1) {
     int j = k >> 1;
@@ -324,7 +258,7 @@ __device__ __forceinline__ void sort_field(const SortArgs &a, int f, uint32_t *s
   for (int r = 0; r < E; ++r) dst[(size_t)tid * E + r] = v[r];
 }
 
-template <int E, bool MERGE>
+template <int E>
 __global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
   extern __shared__ uint32_t sm[];
   const int j = blockIdx.y;  // batch slot of this launch
@@ -332,7 +266,7 @@ __global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
     a.idx += (size_t)((a.pool_first + j) % a.n_pool) * a.pool_stride;
     a.sorted += (size_t)j * a.sorted_stride;
   }
-  sort_field<E, MERGE>(a, blockIdx.x, sm);
+  sort_field<E>(a, blockIdx.x, sm);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1222,15 +1156,9 @@ int check_sort_geometry(const fmx_table_t *t, int B) {
 struct Tune {
   int wpb_fwd = 4, wpb_upd = 4;
   int sort_e = 0;     // FMX_SORT_E: elements per thread of the bitonic sort (0 = default)
-  int ext_events = 0; // FMX_EXT_EVENTS=1: completion events ride on the launches (hipExtLaunchKernel); slower on the host
-  int sort_debug = 0;
   int inline_fixup = 1;  // FMX_INLINE_FIXUP=0 / fmx_set_option("inline_fixup", 0): partial records are combined by a second
                          // launch (k_fm_fixup) instead of the in-launch hand-off; both give identical bits
-  int stream_prio = 1;  // FMX_STREAM_PRIO=0: no stream priorities
   int sort_ahead = 8;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..8)
-  int sort_merge = 0; // FMX_SORT_MERGE=1: in-wave sort + binary-search merge rounds in LDS (measured slower: 31 vs 22 us,
-                      // the merge rounds are LDS-bandwidth bound)
-  int sort_cus = 0;   // FMX_SORT_CUS=n: reserve n CUs for the side-stream sort (CU-masked library streams)
 };
 Tune &tune() {
   static Tune t = [] {
@@ -1238,13 +1166,8 @@ Tune &tune() {
     if (const char *e = getenv("FMX_WPB_FWD")) x.wpb_fwd = atoi(e);
     if (const char *e = getenv("FMX_WPB_UPD")) x.wpb_upd = atoi(e);
     if (const char *e = getenv("FMX_SORT_E")) x.sort_e = atoi(e);
-    if (const char *e = getenv("FMX_EXT_EVENTS")) x.ext_events = atoi(e);
-    if (const char *e = getenv("FMX_SORT_CUS")) x.sort_cus = atoi(e);
-    if (const char *e = getenv("FMX_SORT_MERGE")) x.sort_merge = atoi(e);
-    if (const char *e = getenv("FMX_SORT_DEBUG")) x.sort_debug = atoi(e);
     if (const char *e = getenv("FMX_SORT_AHEAD")) x.sort_ahead = atoi(e);
     if (const char *e = getenv("FMX_INLINE_FIXUP")) x.inline_fixup = atoi(e);
-    if (const char *e = getenv("FMX_STREAM_PRIO")) x.stream_prio = atoi(e);
     auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
     if (!ok(x.wpb_fwd)) x.wpb_fwd = 4;
     if (!ok(x.wpb_upd)) x.wpb_upd = 4;
@@ -1306,29 +1229,11 @@ Side *side_for_current_device() {
   std::lock_guard<std::mutex> lock(mu);
   Side &sd = sides[dev];
   if (!sd.stream) {
-    // Optional CU partition (FMX_SORT_CUS=n): the sort's n workgroup-sized CUs are taken out of the stand-in main
-    // stream's mask, so a sort workgroup never shares a CU with (and never slows down) forward / update workgroups.
-    const int n_sort = tune().sort_cus;
-    hipDeviceProp_t prop;
-    bool masked = false;
-    if (n_sort > 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > n_sort) {
-      const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
-      uint32_t m_side[16] = {0}, m_main[16] = {0};
-      for (int c = 0; c < n_cu && words <= 16; ++c) {
-        if (c < n_sort) m_side[c / 32] |= 1u << (c % 32);
-        else m_main[c / 32] |= 1u << (c % 32);
-      }
-      masked = words <= 16 && hipExtStreamCreateWithCUMask(&sd.stream, words, m_side) == hipSuccess &&
-               hipExtStreamCreateWithCUMask(&sd.main, words, m_main) == hipSuccess;
-    }
-    if (!masked) {
-      // the sort is background work: lowest stream priority for it, highest for the stand-in main stream
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      const bool prio = tune().stream_prio != 0;
-      if (hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, prio ? lo : 0) != hipSuccess) return nullptr;
-      if (hipStreamCreateWithPriority(&sd.main, hipStreamNonBlocking, prio ? hi : 0) != hipSuccess) return nullptr;
-    }
+    // the sort is background work: lowest stream priority for it, highest for the stand-in main stream
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithPriority(&sd.main, hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
     bool ok = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&sd.user_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&sd.user_join, hipEventDisableTiming) == hipSuccess;
@@ -1390,54 +1295,37 @@ void launch_update(const UpdArgs &a, int rule, hipStream_t st) {
   }
 }
 
-template <int LPR, int LAYOUT, int RULE>
-void launch_fixup_k(const UpdArgs &a, dim3 grid, dim3 block, hipStream_t st, hipEvent_t stop) {
-  if (stop) hipExtLaunchKernelGGL((k_fm_fixup<LPR, LAYOUT, RULE>), grid, block, 0, st, nullptr, stop, 0, a);
-  else hipLaunchKernelGGL((k_fm_fixup<LPR, LAYOUT, RULE>), grid, block, 0, st, a);
-}
-
 template <int LPR>
-void launch_fixup(const UpdArgs &a, int rule, hipStream_t st, hipEvent_t stop) {
+void launch_fixup(const UpdArgs &a, int rule, hipStream_t st) {
   const int tiles = a.F * (a.Bp >> 6);
   const int wpb = tune().wpb_upd;
   const dim3 grid((tiles + wpb - 1) / wpb), block(64 * wpb);
   switch (rule) {
-    case FMX_RULE_SIGNADAM: launch_fixup_k<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM>(a, grid, block, st, stop); break;
-    case FMX_RULE_SGD: launch_fixup_k<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD>(a, grid, block, st, stop); break;
-    default: launch_fixup_k<LPR, FMX_LAYOUT_FTRL, FMX_RULE_FTRL>(a, grid, block, st, stop); break;
+    case FMX_RULE_SIGNADAM:
+      hipLaunchKernelGGL((k_fm_fixup<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM>), grid, block, 0, st, a);
+      break;
+    case FMX_RULE_SGD: hipLaunchKernelGGL((k_fm_fixup<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((k_fm_fixup<LPR, FMX_LAYOUT_FTRL, FMX_RULE_FTRL>), grid, block, 0, st, a); break;
   }
 }
 
 template <int LPR>
-void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st, hipEvent_t mid, hipEvent_t stop) {
-  if (tune().inline_fixup && !is_capturing(st)) {  // one launch: the closing tile of a run that crosses tiles sums the partial records itself
+void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st) {
+  if (tune().inline_fixup && !is_capturing(st)) {  // one launch: the closing tile of a crossing run sums the records itself
     if (has_gbi) launch_update<LPR, true, true>(a, rule, st);
     else launch_update<LPR, false, true>(a, rule, st);
-    if (mid) (void)hipEventRecord(mid, st);
-    if (stop) (void)hipEventRecord(stop, st);
     return;
   }
   if (has_gbi) launch_update<LPR, true, false>(a, rule, st);
   else launch_update<LPR, false, false>(a, rule, st);
-  if (mid) (void)hipEventRecord(mid, st);
-  launch_fixup<LPR>(a, rule, st, stop);
-}
-
-template <int E, bool MERGE>
-void launch_sort_m(const SortArgs &a, hipStream_t st, hipEvent_t stop) {
-  const int threads = a.Bp / E;
-  const uint32_t lds = (uint32_t)(a.Bp * sizeof(uint32_t)) * (MERGE ? 2u : 1u);
-  const dim3 grid(a.F, a.n_batches);
-  if (stop)  // the completion event rides on the launch packet: one runtime call instead of launch + hipEventRecord
-    hipExtLaunchKernelGGL((k_sort_occ<E, MERGE>), grid, dim3(threads), lds, st, nullptr, stop, 0, a);
-  else
-    hipLaunchKernelGGL((k_sort_occ<E, MERGE>), grid, dim3(threads), lds, st, a);
+  launch_fixup<LPR>(a, rule, st);
 }
 
 template <int E>
-void launch_sort(const SortArgs &a, hipStream_t st, hipEvent_t stop) {
-  if (a.Bp <= 8192 && tune().sort_merge) launch_sort_m<E, true>(a, st, stop);  // two LDS buffers within 64 KiB
-  else launch_sort_m<E, false>(a, st, stop);
+void launch_sort(const SortArgs &a, hipStream_t st) {
+  const int threads = a.Bp / E;
+  const uint32_t lds = (uint32_t)(a.Bp * sizeof(uint32_t));
+  hipLaunchKernelGGL((k_sort_occ<E>), dim3(a.F, a.n_batches), dim3(threads), lds, st, a);
 }
 
 int prepare_sort(int B) {
@@ -1446,9 +1334,9 @@ int prepare_sort(int B) {
   static bool raised = false;
   std::lock_guard<std::mutex> lock(mu);
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<8>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<16>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_occ<32>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SORT_WIDTH * 4);
     if (e != hipSuccess) return fail(FMX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     raised = true;
   }
@@ -1461,9 +1349,8 @@ struct SortBatch {  // several batches of a pool in one launch
 };
 
 int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t *sorted, int32_t *error, hipStream_t st,
-              hipEvent_t stop = nullptr, const SortBatch *mb = nullptr) {
+              const SortBatch *mb = nullptr) {
   SortArgs a;
-  a.debug = tune().sort_debug;
   a.n_pool = mb ? mb->n_pool : 1;
   a.pool_first = mb ? mb->first : 0;
   a.n_batches = mb ? mb->n_batches : 1;
@@ -1483,12 +1370,12 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
   const int want = tune().sort_e;
   if (want > E && want <= 32 && (want & (want - 1)) == 0 && a.Bp / want >= 64) E = want;
   switch (E) {
-    case 1: launch_sort<1>(a, st, stop); break;
-    case 2: launch_sort<2>(a, st, stop); break;
-    case 4: launch_sort<4>(a, st, stop); break;
-    case 8: launch_sort<8>(a, st, stop); break;
-    case 16: launch_sort<16>(a, st, stop); break;
-    default: launch_sort<32>(a, st, stop); break;
+    case 1: launch_sort<1>(a, st); break;
+    case 2: launch_sort<2>(a, st); break;
+    case 4: launch_sort<4>(a, st); break;
+    case 8: launch_sort<8>(a, st); break;
+    case 16: launch_sort<16>(a, st); break;
+    default: launch_sort<32>(a, st); break;
   }
   return check_launch("k_sort_occ");
 }
@@ -1571,17 +1458,17 @@ UpdArgs fill_upd(const fmx_table_t *table, const fmx_hyper_t *hyper, const Works
 int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const Workspace &w,
                 const uint32_t *sorted, const float *xv,
                 const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
-                const float *loss_b, float inv_b, float *loss_out, hipStream_t st, hipEvent_t mid,
-                int32_t *step_counter = nullptr, hipEvent_t stop = nullptr, int32_t sample_ld = 0,
+                const float *loss_b, float inv_b, float *loss_out, hipStream_t st,
+                int32_t *step_counter = nullptr, int32_t sample_ld = 0,
                 int32_t *err_flag = nullptr) {
   const UpdArgs a = fill_upd(table, hyper, w, sorted, xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out, step_counter,
                              sample_ld, err_flag);
   switch (lpr_of(table->kp)) {
-    case 1: launch_update_pair<1>(a, rule, gbi != nullptr, st, mid, stop); break;
-    case 2: launch_update_pair<2>(a, rule, gbi != nullptr, st, mid, stop); break;
-    case 4: launch_update_pair<4>(a, rule, gbi != nullptr, st, mid, stop); break;
-    case 8: launch_update_pair<8>(a, rule, gbi != nullptr, st, mid, stop); break;
-    default: launch_update_pair<16>(a, rule, gbi != nullptr, st, mid, stop); break;
+    case 1: launch_update_pair<1>(a, rule, gbi != nullptr, st); break;
+    case 2: launch_update_pair<2>(a, rule, gbi != nullptr, st); break;
+    case 4: launch_update_pair<4>(a, rule, gbi != nullptr, st); break;
+    case 8: launch_update_pair<8>(a, rule, gbi != nullptr, st); break;
+    default: launch_update_pair<16>(a, rule, gbi != nullptr, st); break;
   }
   return check_launch("k_fm_update / k_fm_fixup");
 }
@@ -1686,7 +1573,7 @@ int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     return fail(FMX_ERR_ALIGN, "workspace, S, gbi (and dense dz_first / loss_b) must be 16-byte aligned");
   const Workspace w = carve(table, B, workspace);
   return update_impl(table, hyper, rule, w, w.sorted, xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out,
-                     static_cast<hipStream_t>(stream), nullptr, nullptr, nullptr, sample_ld);
+                     static_cast<hipStream_t>(stream), nullptr, sample_ld);
 }
 
 int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
@@ -1709,7 +1596,7 @@ int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
     if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
   }
   return update_impl(table, hyper, rule, w, w.sorted, xv, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b, loss_out, st,
-                     nullptr, nullptr, nullptr, fwd->sample_ld, fwd->error);
+                     nullptr, fwd->sample_ld, fwd->error);
 }
 
 int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
@@ -1755,7 +1642,7 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
       mb.n_batches = n;
       mb.pool_stride = (int64_t)B * (int64_t)F;
       mb.sorted_stride = (int64_t)w.sorted_stride;
-      return sort_impl(table, idx_pool, B, w.sorted + (size_t)(g & 1) * ahead * w.sorted_stride, fwd->error, where, nullptr, &mb);
+      return sort_impl(table, idx_pool, B, w.sorted + (size_t)(g & 1) * ahead * w.sorted_stride, fwd->error, where, &mb);
     };
     const int n_groups = (n_steps + ahead - 1) / ahead;
     if (sd && n_groups > 0) {
@@ -1785,7 +1672,7 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
         if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
         if (rc == FMX_OK)
           rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                           loss_out, st, nullptr, loss_out ? w.counter : nullptr, nullptr, fwd->sample_ld, fwd->error);
+                           loss_out, st, loss_out ? w.counter : nullptr, fwd->sample_ld, fwd->error);
       }
       if (sd) (void)hipEventRecord(sd->consumed[g & 1], st);
     }
@@ -1818,7 +1705,7 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     (void)hipEventRecord(e[2], st);
     for (int r = 0; r < REP && rc == FMX_OK; ++r)
       rc = update_impl(table, hyper, rule, w, w.sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                       loss_out ? loss_out + s : nullptr, st, nullptr, nullptr, nullptr, fwd->sample_ld, fwd->error);
+                       loss_out ? loss_out + s : nullptr, st, nullptr, fwd->sample_ld, fwd->error);
     (void)hipEventRecord(e[3], st);
     (void)hipEventRecord(e[4], st);
   }
