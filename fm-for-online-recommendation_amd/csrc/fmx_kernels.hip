@@ -32,6 +32,12 @@
 
 #include "fmx.h"
 
+// No floating-point contraction: every kernel evaluates the expressions as written (one rounding per operation), so two
+// kernels that state the same arithmetic -- k_fm_forward + k_fm_update at B = 1 and k_fm_online, the update with and
+// without the in-launch hand-off, ... -- give the same bits whatever the surrounding code looks like.  The kernels are
+// bound by memory round trips, not by VALU issue; fused multiply-adds are written explicitly where they are wanted.
+#pragma clang fp contract(off)
+
 // ------------------------------------------------------------------------------------------------------------
 // host-side error plumbing
 // ------------------------------------------------------------------------------------------------------------
@@ -87,7 +93,7 @@ __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(
 
 // FTRL-proximal weight from (z, n)  (McMahan et al. 2013, Algorithm 1); h.alpha holds 1/alpha on the device
 __device__ __forceinline__ float ftrl_w(float z, float n, const fmx_hyper_t &h) {
-  const float denom = (h.beta + sqrt_(n)) * h.alpha + h.l2;
+  const float denom = fmaf(h.beta + sqrt_(n), h.alpha, h.l2);
   const float w = -(z - copysignf(h.l1, z)) * rcp_(denom);
   return fabsf(z) <= h.l1 ? 0.f : w;
 }
@@ -96,9 +102,9 @@ __device__ __forceinline__ float4 ftrl_w4(float4 z, float4 n, const fmx_hyper_t 
 }
 // one FTRL-proximal update of (z, n) by gradient g; w is the weight derived from the OLD (z, n)
 __device__ __forceinline__ void ftrl_upd(float &z, float &n, float w, float g, const fmx_hyper_t &h) {
-  const float n2 = n + g * g;
+  const float n2 = fmaf(g, g, n);
   const float sigma = (sqrt_(n2) - sqrt_(n)) * h.alpha;
-  z = z + g - sigma * w;
+  z = fmaf(-sigma, w, z + g);
   n = n2;
 }
 
@@ -540,6 +546,8 @@ __device__ __forceinline__ RowRegs load_row(const float *rp, int q, int kp, int 
 template <int LAYOUT, int RULE>
 __device__ __forceinline__ void update_row(float *rp, int q, int kp, int zoff, RowRegs r, float4 cV, float4 cA, float cw,
                                            const fmx_hyper_t &h) {
+  // two roundings on purpose (no fma): where a sample is the row's only contribution to S (x = 1), cV = dz * V and
+  // V * cA = V * dz round alike and the gradient is exactly 0, as in the reference's dz * x * (S - e)
   const float4 gr = cV - r.v * cA;
   if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
     *reinterpret_cast<float4 *>(rp + 4 * q) = apply_rule4<RULE>(r.v, gr, h);
@@ -851,6 +859,167 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
     aw += __shfl_xor(aw, mm);
   }
   if (lane < LPR) update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, aV, aA, aw, a.h);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_fm_online: the reference's online protocol on a device-resident stream (pure FM)
+// ------------------------------------------------------------------------------------------------------------
+// run_experiment (reference fm_adam.py:90-119): for every sample, predict (sigmoid(forward) > 0.5), then fit on that
+// one sample.  Steps of one sample are inherently sequential (step i+1 reads the rows step i wrote), so ONE wavefront
+// walks the stream: per sample it gathers the F rows (sc1 loads: a row may have been written by the previous sample),
+// evaluates the logit, stores the prediction, and applies the rule to the same rows from registers -- the arithmetic of
+// k_fm_forward + k_fm_update at B = 1 (each row of a sample is a run of one occurrence), so the tables end
+// bit-identical to N calls of fmx_fm_step with B = 1.  The next sample's indices are fetched while the current one is
+// processed; the bias lives in registers.  Per sample: one dependent gather + the store acknowledgement (~3 us).
+struct OnlineArgs {
+  float *rows;
+  const int64_t *foff;
+  float *bias;
+  const int32_t *idx;  // [N, F]
+  const float *xv;     // [N, F] or null
+  const float *y;      // [N]
+  uint8_t *pred;       // [N] sigmoid(logit) > 0.5 BEFORE the sample's update
+  float *loss;         // [N] or null
+  int32_t *error;
+  fmx_hyper_t h;
+  int32_t N, F, stride, zoff, loss_kind;
+};
+
+template <int LAYOUT>
+__device__ __forceinline__ RowRegs load_row_sc1(const float *rp, int q, int kp, int zoff) {
+  RowRegs r;
+  r.v = ld_sc1_4(rp + 4 * q);
+  r.z = splat(0.f);
+  r.n = splat(0.f);
+  r.fo = splat(0.f);
+  if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
+    if (q == 0) r.fo.x = ld_sc1(rp + kp);
+  } else {
+    r.z = ld_sc1_4(rp + zoff + 4 * q);
+    r.n = ld_sc1_4(rp + zoff + kp + 4 * q);
+    if (q == 0) r.fo = ld_sc1_4(rp + kp);
+  }
+  return r;
+}
+
+template <int LPR, int LAYOUT, int RULE, int NP>
+__global__ __launch_bounds__(64) void k_fm_online(OnlineArgs a) {
+  constexpr int SLOTS = WAVE / LPR;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, q = lane % LPR;
+  const int kp = LPR * 4;
+  float b0 = a.bias[0], b1 = LAYOUT == FMX_LAYOUT_FTRL ? a.bias[1] : 0.f;  // the bias (or its (z, n)) stays in registers
+  int64_t lo[NP];
+  uint32_t vocab[NP];
+  bool live[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int f = p * SLOTS + slot;
+    live[p] = f < a.F;
+    lo[p] = live[p] ? a.foff[f] : 0;
+    vocab[p] = live[p] ? (uint32_t)(a.foff[f + 1] - lo[p]) : 0u;
+  }
+  uint32_t li_n[NP];
+  float x_n[NP], y_n = 0.f;
+  auto fetch_inputs = [&](int i) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      li_n[p] = 0;
+      x_n[p] = 1.f;
+      if (live[p] && i < a.N) {
+        const size_t o = (size_t)i * a.F + p * SLOTS + slot;
+        li_n[p] = (uint32_t)a.idx[o];
+        if (a.xv) x_n[p] = a.xv[o];
+      }
+    }
+    y_n = i < a.N ? a.y[i] : 0.f;
+  };
+  fetch_inputs(0);
+  bool bad = false;
+  for (int i = 0; i < a.N; ++i) {
+    uint32_t li[NP];
+    float x[NP];
+    const float y = y_n;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      li[p] = li_n[p];
+      x[p] = x_n[p];
+    }
+    RowRegs row[NP];
+    bool ok[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      ok[p] = live[p] && li[p] < vocab[p];
+      row[p].v = splat(0.f);
+      row[p].z = splat(0.f);
+      row[p].n = splat(0.f);
+      row[p].fo = splat(0.f);
+      if (ok[p]) row[p] = load_row_sc1<LAYOUT>(a.rows + (size_t)(lo[p] + li[p]) * a.stride, q, kp, a.zoff);
+      else if (live[p]) bad = true;
+    }
+    fetch_inputs(i + 1);  // independent of the weights: in flight while this sample is processed
+    // ---- forward: the arithmetic of k_fm_forward ----
+    float4 s = splat(0.f), ss = splat(0.f);
+    float fo = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (ok[p]) {
+        const float4 e = x[p] * row[p].v;
+        s = s + e;
+        ss = ss + e * e;
+        fo += row[p].fo.x * x[p];
+      }
+    }
+#define FMX_BFLY(M)                               \
+  if (LPR <= M) {                                 \
+    s = s + xor_lane_f4<M>(s, lane);              \
+    ss = ss + xor_lane_f4<M>(ss, lane);           \
+    fo += xor_lane_f<M>(fo, lane);                \
+  }
+    FMX_BFLY(1) FMX_BFLY(2) FMX_BFLY(4) FMX_BFLY(8) FMX_BFLY(16) FMX_BFLY(32)
+#undef FMX_BFLY
+    const float4 bi = 0.5f * (s * s - ss);
+    float sbi = (bi.x + bi.y) + (bi.z + bi.w);
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) sbi += __shfl_xor(sbi, m);
+    fo = __shfl(fo, 0);
+    const float bias_w = LAYOUT == FMX_LAYOUT_WEIGHTS ? b0 : ftrl_w(b0, b1, a.h);
+    const float z = fo + sbi + bias_w;
+    float loss, dz;
+    if (a.loss_kind == FMX_LOSS_BCE_LOGITS) {
+      loss = bcewl(z, y);
+      dz = sigmoidf_(z) - y;
+    } else {
+      const float pz = sigmoidf_(z);
+      loss = bcewl(pz, y);
+      dz = (sigmoidf_(pz) - y) * pz * (1.f - pz);
+    }
+    if (lane == 0) {
+      a.pred[i] = sigmoidf_(z) > 0.5f ? 1 : 0;
+      if (a.loss) a.loss[i] = loss;
+    }
+    // ---- fit: every row of the sample is a run of one occurrence (k_fm_update's sums with B = 1, inv_b = 1) ----
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (ok[p]) {
+        const float xG = x[p] * dz;
+        update_row<LAYOUT, RULE>(a.rows + (size_t)(lo[p] + li[p]) * a.stride, q, kp, a.zoff, row[p], xG * s, splat(x[p] * xG),
+                                 xG, a.h);
+      }
+    }
+    if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
+      b0 = apply_rule<RULE>(b0, dz, a.h);
+    } else {
+      const float w = ftrl_w(b0, b1, a.h);
+      ftrl_upd(b0, b1, w, dz, a.h);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row stores are acknowledged before the next sample's loads
+  }
+  if (lane == 0) {
+    a.bias[0] = b0;
+    if (LAYOUT == FMX_LAYOUT_FTRL) a.bias[1] = b1;
+    if (bad && a.error) *a.error = 1;
+  }
 }
 
 // Runs that cross tile boundaries: the wave of the tile holding the run's head adds the partial sums in tile order
@@ -1473,6 +1642,25 @@ int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
   return check_launch("k_fm_update / k_fm_fixup");
 }
 
+template <int LPR, int LAYOUT, int RULE>
+void launch_online_np(const OnlineArgs &a, int np, hipStream_t st) {
+  switch (np) {
+    case 1: hipLaunchKernelGGL((k_fm_online<LPR, LAYOUT, RULE, 1>), dim3(1), dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_fm_online<LPR, LAYOUT, RULE, 2>), dim3(1), dim3(64), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_fm_online<LPR, LAYOUT, RULE, 3>), dim3(1), dim3(64), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_fm_online<LPR, LAYOUT, RULE, 4>), dim3(1), dim3(64), 0, st, a); break;
+  }
+}
+
+template <int LPR>
+void launch_online(const OnlineArgs &a, int rule, int np, hipStream_t st) {
+  switch (rule) {
+    case FMX_RULE_SIGNADAM: launch_online_np<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM>(a, np, st); break;
+    case FMX_RULE_SGD: launch_online_np<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD>(a, np, st); break;
+    default: launch_online_np<LPR, FMX_LAYOUT_FTRL, FMX_RULE_FTRL>(a, np, st); break;
+  }
+}
+
 int check_forward_args(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *y, int32_t B,
                        int32_t loss_kind, const fmx_fwd_out_t *out) {
   if (int rc = check_table(table)) return rc;
@@ -1731,6 +1919,48 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
   for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventDestroy(ev[i]);
   delete[] ev;
   return rc;
+}
+
+int fmx_fm_online_run(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
+                      const int32_t *idx, const float *xv, const float *y, int32_t N, uint8_t *pred_out, float *loss_out,
+                      int32_t *error, fmx_stream_t stream) {
+  if (int rc = check_table(table)) return rc;
+  if (int rc = check_rule(table, rule)) return rc;
+  if (!hyper || !idx || !y || !pred_out) return fail(FMX_ERR_ARG, "fmx_fm_online_run: null argument");
+  if (N < 0) return fail(FMX_ERR_ARG, "fmx_fm_online_run: N must be >= 0");
+  if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "fit needs a loss");
+  const int lpr = lpr_of(table->kp), slots = WAVE / lpr;
+  const int np = (table->n_fields + slots - 1) / slots;
+  if (np > 4)
+    return fail(FMX_ERR_UNSUPPORTED, "fmx_fm_online_run: %d fields at kp = %d exceed the %d rows one wavefront holds", table->n_fields,
+                table->kp, 4 * slots);
+  if (N == 0) return FMX_OK;
+  OnlineArgs a;
+  a.rows = table->rows;
+  a.foff = table->field_offsets;
+  a.bias = table->bias;
+  a.idx = idx;
+  a.xv = xv;
+  a.y = y;
+  a.pred = pred_out;
+  a.loss = loss_out;
+  a.error = error;
+  a.h = *hyper;
+  a.h.alpha = 1.0f / hyper->alpha;  // the kernels multiply by 1/alpha
+  a.N = N;
+  a.F = table->n_fields;
+  a.stride = table->row_stride;
+  a.zoff = table->z_offset;
+  a.loss_kind = loss_kind;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (lpr) {
+    case 1: launch_online<1>(a, rule, np, st); break;
+    case 2: launch_online<2>(a, rule, np, st); break;
+    case 4: launch_online<4>(a, rule, np, st); break;
+    case 8: launch_online<8>(a, rule, np, st); break;
+    default: launch_online<16>(a, rule, np, st); break;
+  }
+  return check_launch("k_fm_online");
 }
 
 static int mlp_launch(const fmx_mlp_t *mlp, MlpArgs &a, int32_t B, int32_t kp, fmx_stream_t stream, const char *who) {

@@ -206,6 +206,21 @@ class FMEngine:
         _lib.check(self.lib.fmx_mlp_hedge_fit(C.byref(m), lr, hedge_b, hedge_s, alpha.data_ptr(), self.bi.data_ptr(),
                                               self.table.kp, base.data_ptr(), y_d.data_ptr(), B, None, self._stream()))
 
+    def online_run(self, hyper, rule, loss, idx_d, xv_d, y_d, want_loss=False):
+        """The reference's online protocol for pure FM on N device-resident samples (fmx_fm_online_run): per sample
+        predict, then fit on that sample.  -> (pred uint8 [N], loss [N] or None)."""
+        N = idx_d.shape[0]
+        pred = torch.empty(N, dtype=torch.uint8, device=self.device)
+        loss_b = torch.empty(N, dtype=torch.float32, device=self.device) if want_loss else None
+        _lib.check(self.lib.fmx_fm_online_run(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss],
+                                              idx_d.data_ptr(), _ptr(xv_d), y_d.data_ptr(), N, pred.data_ptr(), _ptr(loss_b),
+                                              self.error.data_ptr(), self._stream()))
+        return pred, loss_b
+
+    @staticmethod
+    def online_run_fits(n_fields, kp):
+        return n_fields <= 4 * (64 // (kp // 4))
+
     def mlp_section(self, params, grads, k, hidden, n_layers, loss, bi, base, y_d, B, inv_b, lr_apply=0.0):
         """The MLP on `bi` at mini-batch sizes (fmx_mlp_section: fp32 MFMA GEMMs): forward, loss, backward.
         -> (loss [1], dz [B], gbi [B, kp]); `grads` (flat, the layout of `params`) is filled; lr_apply != 0 also applies SGD."""

@@ -190,6 +190,16 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
                   int32_t n_steps, void *workspace, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
                   fmx_stream_t stream);
 
+/* The reference's online protocol for the pure-FM class on a device-resident stream of N samples: for every sample,
+ * predict (pred_out[i] = sigmoid(logit) > 0.5 with the weights BEFORE the sample's update), then one fit step on that
+ * sample alone (B = 1, inv_b = 1) under `rule` and `loss_kind`.  One wavefront walks the stream (the steps are sequential by
+ * definition); the table and bias end bit-identical to N calls of fmx_fm_step with B = 1.  loss_out [N] may be null.
+ * Needs n_fields <= 4 * (64 / (kp / 4)) (64 fields at kp = 16), else FMX_ERR_UNSUPPORTED.
+ * Replaces: FMAdam.run_experiment's loop body (reference fm_adam.py:97-99: predict at :84-88, fit at :71-82). */
+int fmx_fm_online_run(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
+                      const int32_t *idx, const float *xv, const float *y, int32_t N, uint8_t *pred_out, float *loss_out,
+                      int32_t *error, fmx_stream_t stream);
+
 /* ---- the small relu MLP on top of the bi-interaction vector (online steps of DeepFM / NFM and the ONN classes) ----
  * params: per layer W [out, in] row-major then b [out]; layer 0 maps k -> hidden, the others hidden -> hidden; the network's
  * contribution to the logit is the sum of the last activation (reference deepfm_adam.py:82-88: there is no output layer).

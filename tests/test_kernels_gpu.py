@@ -534,3 +534,42 @@ def test_inline_fixup_matches_second_launch_small_shapes(fmx, k, B, rule):
             lib.fmx_set_option(b"inline_fixup", prev)
     for a, b in zip(res[0], res[1]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("rule,k,real_x", [("signadam", 10, False), ("sgd", 4, True), ("ftrl", 16, False), ("ftrl", 8, True)])
+def test_online_run_equals_single_sample_steps(fmx, rule, k, real_x):
+    """fmx_fm_online_run (one wavefront walking the stream: predict, then fit, per sample) leaves the table bit-identical
+    to N calls of fmx_fm_step with B = 1, and its predictions are sigmoid(logit) > 0.5 of the forward before each step."""
+    sizes, N = MIXED_SIZES, 300
+    pr = make_problem(sizes, k, N, seed=77, real_x=real_x, zipf=True)        # skewed: consecutive samples share rows
+    loss_kind = "sigmoid"
+
+    def table():
+        if rule == "ftrl":
+            t = fmx.FlatTable(sizes, k, layout="ftrl", ftrl=HYP)
+            V0 = torch.from_numpy(pr["V"]).cuda()
+            t.rows[:, :k] = V0
+            t.rows[:, t.z_offset:t.z_offset + k] = fmx.table.ftrl_z_for_weight_torch(V0, t.ftrl)
+            return t
+        return weights_table(fmx, sizes, k, pr)
+    hyp = fmx.Hyper(**HYP)
+    t1 = table()
+    e1 = fmx.FMEngine(t1, max_batch=N)
+    idx_d, xv_d, y_d = e1.to_device(pr["idx"], pr["x"] if real_x else None, pr["y"])
+    pred, loss_b = e1.online_run(hyp, rule, loss_kind, idx_d, xv_d, y_d, want_loss=True)
+    torch.cuda.synchronize()
+    e1.check_error_flag()
+    t2 = table()
+    e2 = fmx.FMEngine(t2, max_batch=8)
+    preds2, losses2 = [], []
+    for i in range(N):
+        xi = xv_d[i:i + 1] if xv_d is not None else None
+        e2.forward(hyp, idx_d[i:i + 1], xi, want_first=False, want_bi=False)
+        preds2.append(bool(torch.sigmoid(e2.logit[0]) > 0.5))
+        e2.step(hyp, rule, loss_kind, idx_d[i:i + 1], xi, y_d[i:i + 1])
+        losses2.append(float(e2.loss_out.item()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(t1.rows.cpu().numpy(), t2.rows.cpu().numpy())
+    np.testing.assert_array_equal(t1.bias.cpu().numpy(), t2.bias.cpu().numpy())
+    np.testing.assert_array_equal(loss_b.cpu().numpy(), np.asarray(losses2, dtype=np.float32))
+    assert pred.cpu().numpy().astype(bool).tolist() == preds2
