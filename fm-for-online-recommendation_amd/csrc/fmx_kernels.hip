@@ -1101,7 +1101,11 @@ struct MlpArgs {
   float *gbi_out;      // FIT: [B, kp]
   float *out;          // FORWARD: [B] logit (adam classes) ; FIT: [1] mean loss or null
   float *layers_out;   // FORWARD: [L, B] sigmoid(base + sum x_l) or null ; HEDGE: [L] losses or null
+  float *pred_out;     // FIT: [B] the logit, HEDGE: [B] sigmoid(last layer's logit) -- what forward() returns, before the update; or null
+  const float *base_bias;  // null, or the table's bias words: base[b] + bias weight is the logit without the MLP term (NFM)
+  int32_t base_bias_ftrl;  // base_bias holds (z, n) of an FTRL table instead of the weight
   fmx_hyper_t h;       // lr / eps (FIT: rule) ; HEDGE: lr = n
+  fmx_hyper_t h_table; // base_bias_ftrl: the table's FTRL hyper-parameters (alpha already inverted)
   float hedge_b, hedge_s;
   int32_t B, k, kp, hidden, n_layers, mode, rule, loss_kind;
   float inv_b;
@@ -1147,7 +1151,10 @@ __global__ __launch_bounds__(256) void k_mlp_small(MlpArgs a) {
     if (need) {
       float s = 0.f;
       for (int j = 0; j < H; ++j) s += X(l + 1, b, j);
-      const float z = a.base[b] + s;
+      float base_b = a.base[b];
+      if (a.base_bias) base_b += a.base_bias_ftrl ? ftrl_w(a.base_bias[0], a.base_bias[1], a.h_table) : a.base_bias[0];
+      const float z = base_b + s;
+      if (a.pred_out && l == L - 1 && a.mode != MLP_MODE_FORWARD) a.pred_out[b] = a.mode == MLP_MODE_HEDGE ? sigmoidf_(z) : z;
       if (a.mode == MLP_MODE_FORWARD) {
         if (a.layers_out) a.layers_out[(size_t)l * B + b] = sigmoidf_(z);
         if (l == L - 1 && a.out) a.out[b] = z;
@@ -1977,6 +1984,71 @@ static int mlp_launch(const fmx_mlp_t *mlp, MlpArgs &a, int32_t B, int32_t kp, f
   a.n_layers = mlp->n_layers;
   hipLaunchKernelGGL(k_mlp_small, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch("k_mlp_small");
+}
+
+int fmx_online_run_mlp(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
+                       const fmx_mlp_t *mlp, int32_t hedge, int32_t fm_term, float hedge_b, float hedge_s, float *alpha,
+                       const int32_t *idx, const float *xv, const float *y, int32_t N, void *workspace,
+                       const fmx_fwd_out_t *fwd, float *scratch, float *pred_out, fmx_stream_t stream) {
+  if (int rc = check_table(table)) return rc;
+  if (!hyper || !mlp || !idx || !y || !workspace || !fwd || !scratch || !pred_out)
+    return fail(FMX_ERR_ARG, "fmx_online_run_mlp: null argument");
+  if (!fwd->S || !fwd->bi || !fwd->sfirst || !fwd->logit) return fail(FMX_ERR_ARG, "fmx_online_run_mlp: fwd needs S, bi, sfirst, logit");
+  if (!aligned16(workspace) || !aligned16(scratch)) return fail(FMX_ERR_ALIGN, "workspace and scratch must be 16-byte aligned");
+  if (hedge && !alpha) return fail(FMX_ERR_ARG, "fmx_online_run_mlp: Hedge needs alpha");
+  if (!hedge) {
+    if (int rc = check_rule(table, rule)) return rc;
+    if (rule != FMX_RULE_SIGNADAM && rule != FMX_RULE_SGD) return fail(FMX_ERR_ARG, "fmx_online_run_mlp: rule must be SIGNADAM or SGD");
+    if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "fit needs a loss");
+    if (mlp->k > MLP_MAX_W - 1) return fail(FMX_ERR_UNSUPPORTED, "fmx_online_run_mlp: k <= %d", MLP_MAX_W - 1);
+    if (int rc = check_sort_geometry(table, 1)) return rc;
+  } else if (mlp->k + mlp->n_layers > MLP_MAX_W) {
+    return fail(FMX_ERR_UNSUPPORTED, "fmx_online_run_mlp: k + layers <= %d", MLP_MAX_W);
+  }
+  if (N < 0) return fail(FMX_ERR_ARG, "N must be >= 0");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const Workspace w = carve(table, 1, workspace);
+  const size_t F = (size_t)table->n_fields;
+  fmx_fwd_out_t f1 = *fwd;  // one sample: dense outputs
+  f1.sample_ld = 0;
+  float *dz = scratch, *gbi = scratch + 8;
+  for (int i = 0; i < N; ++i) {
+    const int32_t *idx_i = idx + (size_t)i * F;
+    const float *xv_i = xv ? xv + (size_t)i * F : nullptr;
+    if (int rc = forward_impl(table, hyper, idx_i, xv_i, nullptr, 1, FMX_LOSS_NONE, 1.0f, &f1, st)) return rc;
+    MlpArgs a{};
+    a.bi = fwd->bi;
+    a.base = fm_term ? fwd->logit : fwd->sfirst;
+    if (!fm_term) {  // NFM: the logit without the MLP term is the first-order sum plus the bias weight
+      a.base_bias = table->bias;
+      a.base_bias_ftrl = table->layout == FMX_LAYOUT_FTRL;
+      a.h_table = *hyper;
+      a.h_table.alpha = 1.0f / hyper->alpha;
+    }
+    a.y = y + i;
+    a.pred_out = pred_out + i;
+    a.h = *hyper;
+    a.inv_b = 1.0f;
+    if (hedge) {
+      a.alpha = alpha;
+      a.hedge_b = hedge_b;
+      a.hedge_s = hedge_s;
+      a.mode = MLP_MODE_HEDGE;
+    } else {
+      a.dz_out = dz;
+      a.gbi_out = gbi;
+      a.mode = MLP_MODE_FIT;
+      a.rule = rule;
+      a.loss_kind = loss_kind;
+    }
+    if (int rc = mlp_launch(mlp, a, 1, table->kp, stream, "fmx_online_run_mlp")) return rc;
+    if (hedge) continue;  // Hedge trains the hidden layers and alpha only (reference deepfm_onn.py:109-154)
+    if (int rc = sort_impl(table, idx_i, 1, w.sorted, fwd->error, st)) return rc;
+    if (int rc = update_impl(table, hyper, rule, w, w.sorted, xv_i, fwd->S, dz, fm_term ? dz : nullptr, gbi, 1, nullptr, 1.0f, nullptr,
+                             st, nullptr, 0, fwd->error))
+      return rc;
+  }
+  return FMX_OK;
 }
 
 int fmx_mlp_forward(const fmx_mlp_t *mlp, const float *bi, int32_t kp, const float *base, int32_t B, float *out,

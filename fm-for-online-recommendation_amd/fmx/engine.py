@@ -217,6 +217,22 @@ class FMEngine:
                                               self.error.data_ptr(), self._stream()))
         return pred, loss_b
 
+    def online_run_mlp(self, hyper, rule, loss, params, k, hidden, n_layers, hedge, fm_term, hedge_b, hedge_s, alpha,
+                       idx_d, xv_d, y_d):
+        """The online protocol for the classes with an MLP (fmx_online_run_mlp) -> forward() value per sample [N]."""
+        N = idx_d.shape[0]
+        self._ensure(1)
+        out = self._fwd_out(want_first=False, want_bi=True)
+        m = self._mlp_struct(params, k, hidden, n_layers)
+        pred = torch.empty(N, dtype=torch.float32, device=self.device)
+        if getattr(self, "_online_scratch", None) is None:
+            self._online_scratch = torch.zeros(self.table.kp + 8, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.fmx_online_run_mlp(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss], C.byref(m),
+                                               1 if hedge else 0, 1 if fm_term else 0, hedge_b, hedge_s, _ptr(alpha),
+                                               idx_d.data_ptr(), _ptr(xv_d), y_d.data_ptr(), N, self.workspace.data_ptr(),
+                                               C.byref(out), self._online_scratch.data_ptr(), pred.data_ptr(), self._stream()))
+        return pred
+
     @staticmethod
     def online_run_fits(n_fields, kp):
         return n_fields <= 4 * (64 // (kp // 4))

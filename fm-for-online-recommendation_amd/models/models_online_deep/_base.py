@@ -352,8 +352,53 @@ class OnlineFMBase(nn.Module):
         pred = torch.sigmoid(out).cpu()
         return pred.data.numpy() > 0.5
 
+    def _device_loop_ok(self):
+        """Can run_experiment's predict-then-fit loop run on the device for this model?"""
+        if not getattr(self, "device_online_loop", True):
+            return False
+        e, k = self._engine, self.embedding_size
+        if not self._has_mlp:
+            return e.online_run_fits(self.field_size, self._table.kp)
+        H, L = self.neuron_per_hidden_layer, self.num_hidden_layers
+        if self._onn:
+            return self.batch_size == 1 and e.mlp_fits(1, k, H, L, "hedge")
+        return self.update_rule != "ftrl" and e.mlp_fits(1, k, H, L, "fit")
+
+    def _run_experiment_on_device(self, data_Xi, data_Xv, data_Y):
+        """The whole predict-then-fit loop on the device, same arithmetic as predict() + fit() per sample: pure FM as one
+        wavefront walking the stream (fmx_fm_online_run); the MLP classes as the per-sample launches queued back to back
+        without host synchronisation (fmx_online_run_mlp).  The confusion matrix and its checkpoints are then counted on
+        the host from the per-sample predictions, in the reference's order."""
+        start = time()
+        idx_d, xv_d, y_d = self._inputs(data_Xi, data_Xv, data_Y)
+        self.train()
+        e = self._engine
+        if not self._has_mlp:
+            pred, _ = e.online_run(self._hyper, self.update_rule, self._loss_fit, idx_d, xv_d, y_d)
+            pred = pred.cpu().numpy().astype(bool)
+        else:
+            out = e.online_run_mlp(self._hyper, self.update_rule, self._loss_fit, self._mlp_flat, self.embedding_size,
+                                   self.neuron_per_hidden_layer, self.num_hidden_layers, self._onn, self._fm_term_in_forward,
+                                   float(self.b.detach()) if self._onn else 0.0, float(self.s.detach()) if self._onn else 0.0,
+                                   self.alpha if self._onn else None, idx_d, xv_d, y_d)
+            pred = (torch.sigmoid(out) > 0.5).cpu().numpy()          # predict(): sigmoid of what forward() returns
+        e.check_error_flag()
+        y = np.asarray(data_Y).reshape(-1)
+        accuracy, roc = [], []
+        n = len(y)
+        pos, hit = y == 1, pred == (y == 1)      # `pred == data_Y[i]` in the reference: a bool against a 0/1 label
+        tp, fn = np.cumsum(pos & hit), np.cumsum(pos & ~hit)
+        tn, fp = np.cumsum(~pos & hit), np.cumsum(~pos & ~hit)
+        for i in sorted(set(range(0, n, 1000)) | {n - 1}):
+            roc.append({"tpr": tp[i] / (tp[i] + fn[i] + 1e-16), "fpr": fp[i] / (fp[i] + tn[i] + 1e-16)})
+            accuracy.append((tp[i] + tn[i]) / (i + 1) * 100)
+        cm = {"tp": int(tp[-1]), "fp": int(fp[-1]), "tn": int(tn[-1]), "fn": int(fn[-1])}
+        return time() - start, float(accuracy[-1]), {k: float(v) for k, v in roc[-1].items()}, cm
+
     def run_experiment(self, data_Xi, data_Xv, data_Y):
         data_size = len(data_Y)
+        if data_size > 0 and self._device_loop_ok():
+            return self._run_experiment_on_device(data_Xi, data_Xv, data_Y)
         confusion_matrix = {"tp": 0, "fp": 0, "tn": 0, "fn": 0}
         accuracy, roc = [], []
         start = time()

@@ -229,6 +229,19 @@ int fmx_mlp_fit(const fmx_mlp_t *mlp, const fmx_hyper_t *hyper, int32_t rule, in
 int fmx_mlp_hedge_fit(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge_s, float *alpha, const float *bi, int32_t kp,
                       const float *base, const float *y, int32_t B, float *losses_out, fmx_stream_t stream);
 
+/* The reference's online protocol for the classes with an MLP on a device-resident stream of N samples: per sample the
+ * forward (pred_out[i] = what forward() returns: the logit for the Adam classes, sigmoid of the last layer's logit for
+ * the ONN classes), then fit on that sample -- hedge = 0: fmx_mlp_fit + the table update (DeepFMAdam / NFMAdam.fit),
+ * hedge = 1: fmx_mlp_hedge_fit (the ONN classes: hidden layers and alpha only).  fm_term: the FM logit is part of the
+ * network's input logit (DeepFM) or only the first-order sum and the bias (NFM).  The launches of all samples are queued
+ * without any host synchronisation (2 per sample with Hedge, 4 otherwise).  workspace: fmx_workspace_bytes(table, 1);
+ * fwd: S, bi, sfirst, logit of at least one sample; scratch: >= kp + 8 floats, 16-byte aligned.
+ * Replaces: the loop body of run_experiment (reference deepfm_adam.py:128-130, deepfm_onn.py:178-180, ...). */
+int fmx_online_run_mlp(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
+                       const fmx_mlp_t *mlp, int32_t hedge, int32_t fm_term, float hedge_b, float hedge_s, float *alpha,
+                       const int32_t *idx, const float *xv, const float *y, int32_t N, void *workspace,
+                       const fmx_fwd_out_t *fwd, float *scratch, float *pred_out, fmx_stream_t stream);
+
 /* The same network at mini-batch sizes (BASELINE configs[3]: 3 x 256, B = 4096), any B / hidden / k, up to 8 layers:
  * forward, loss on (base + sum_j x_L[j]), backward -- fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32: exact f32 products and
  * accumulation), deterministic (split-K partials summed in a fixed order, no atomics).

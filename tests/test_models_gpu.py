@@ -343,3 +343,22 @@ def test_driver_script_flow_end_to_end(tmp_path, capsys):
         m = pickle.load(f)                                # our own file, written a moment ago
     assert str(m).startswith("FMAdam-")
     assert len(list((tmp_path / "save_log").iterdir())) == 1
+
+
+@pytest.mark.parametrize("name", CLASS_NAMES)
+def test_device_online_loop_equals_per_sample_loop(name):
+    """run_experiment on the device (fmx_fm_online_run / fmx_online_run_mlp) against the literal per-sample loop of
+    predict() + fit() calls: the same 4-tuple (minus the time) and bit-identical parameters."""
+    z, meta = load_model_fixture(name, "criteo39s")
+    Xi, Xv, Y = z["B/Xi"].tolist(), z["B/Xv"].tolist(), z["B/Y"].tolist()
+    res = []
+    for on_device in (True, False):
+        m = build(name, meta, 1)
+        m.load_state_dict(sub(z, "B/sd0"))
+        m.device_online_loop = on_device
+        assert m._device_loop_ok() == on_device
+        t, acc, roc, cm = m.run_experiment(Xi, Xv, Y)
+        res.append((acc, roc, cm, sd_np(m)))
+    assert res[0][:3] == res[1][:3]
+    for k in res[1][3]:
+        np.testing.assert_array_equal(res[0][3][k], res[1][3][k], err_msg=k)
