@@ -2103,6 +2103,61 @@ int fmx_mlp_hedge_fit(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge
   return mlp_launch(mlp, a, B, kp, stream, "fmx_mlp_hedge_fit");
 }
 
+// the forward GEMM chain of the mini-batch MLP: acts[l] = relu(acts[l-1] . W_l^T + b_l)
+static void mlp_big_forward(const fmx_mlp_t *mlp, const MlpBigWs &w, const float *bi, int32_t ld_bi, int32_t B, hipStream_t st) {
+  const int L = mlp->n_layers, H = mlp->hidden, k = mlp->k;
+  const size_t act = align_up((size_t)B * H * 4, 256) / 4;
+  long long o = 0;
+  for (int l = 0; l < L; ++l) {
+    const int in = l == 0 ? k : H;
+    GemmArgs g;
+    g.mask = nullptr;
+    g.ldmask = 0;
+    g.c_split_stride = 0;
+    g.zero_cols_to = 0;
+    g.A = l == 0 ? bi : w.acts + (size_t)(l - 1) * act;
+    g.lda = l == 0 ? ld_bi : H;
+    g.Bm = mlp->params + o;
+    g.ldb = in;
+    g.C = w.acts + (size_t)l * act;
+    g.ldc = H;
+    g.bias = mlp->params + o + (long long)H * in;
+    g.M = B;
+    g.N = H;
+    g.K = in;
+    g.k_chunk = in;
+    g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
+    g.b_bytes = (unsigned)((size_t)H * g.ldb * 4);
+    g.vec = (size_t)B * g.lda * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 0, 1);
+    launch_gemm<0, 1, EPI_BIAS_RELU>(g, 1, st);
+    o += (long long)H * in + H;
+  }
+}
+
+int fmx_mlp_forward_batch(const fmx_mlp_t *mlp, const float *bi, int32_t ld_bi, const float *base, int32_t B, void *workspace,
+                          float *logit_out, float *layers_out, fmx_stream_t stream) {
+  if (!mlp || !mlp->params || !bi || !base || !workspace || (!logit_out && !layers_out))
+    return fail(FMX_ERR_ARG, "fmx_mlp_forward_batch: null argument");
+  if (mlp->n_layers < 1 || mlp->n_layers > MLP_BIG_MAX_L || mlp->k < 1 || mlp->hidden < 1 || B < 1)
+    return fail(FMX_ERR_UNSUPPORTED, "fmx_mlp_forward_batch: needs 1 <= layers <= %d, k >= 1, hidden >= 1, B >= 1", MLP_BIG_MAX_L);
+  if (ld_bi < mlp->k) return fail(FMX_ERR_SHAPE, "fmx_mlp_forward_batch: ld_bi smaller than k");
+  if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const MlpBigWs w = mlp_big_carve(mlp, B, workspace);
+  mlp_big_forward(mlp, w, bi, ld_bi, B, st);
+  MlpOutArgs a;
+  a.acts = w.acts;
+  a.act_stride = align_up((size_t)B * mlp->hidden * 4, 256) / 4;
+  a.base = base;
+  a.logit = logit_out;
+  a.layers = layers_out;
+  a.B = B;
+  a.hidden = mlp->hidden;
+  a.n_layers = mlp->n_layers;
+  hipLaunchKernelGGL(k_mlp_outputs, dim3((B + 3) / 4), dim3(256), 0, st, a);
+  return check_launch("fmx_mlp_forward_batch");
+}
+
 int64_t fmx_mlp_section_workspace_bytes(const fmx_mlp_t *mlp, int32_t B) {
   if (!mlp || mlp->n_layers < 1 || mlp->n_layers > MLP_BIG_MAX_L || mlp->k < 1 || mlp->hidden < 1 || B < 1)
     return fail(FMX_ERR_ARG, "fmx_mlp_section_workspace_bytes: bad mlp / B");
@@ -2145,25 +2200,7 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     return g;
   };
   // ---- forward ----
-  for (int l = 0; l < L; ++l) {
-    const int in = l == 0 ? k : H;
-    GemmArgs g = base_args();
-    g.A = l == 0 ? bi : w.acts + (size_t)(l - 1) * act;
-    g.lda = l == 0 ? ld_bi : H;
-    g.Bm = Wl[l];
-    g.ldb = in;
-    g.C = w.acts + (size_t)l * act;
-    g.ldc = H;
-    g.bias = bl[l];
-    g.M = B;
-    g.N = H;
-    g.K = in;
-    g.k_chunk = in;
-    g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
-    g.b_bytes = (unsigned)((size_t)H * g.ldb * 4);
-    g.vec = (size_t)B * g.lda * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 0, 1);
-    launch_gemm<0, 1, EPI_BIAS_RELU>(g, 1, st);
-  }
+  mlp_big_forward(mlp, w, bi, ld_bi, B, st);
   // ---- loss, dL/dlogit, dH_L ----
   {
     MlpLossArgs a;

@@ -237,10 +237,7 @@ class FMEngine:
     def online_run_fits(n_fields, kp):
         return n_fields <= 4 * (64 // (kp // 4))
 
-    def mlp_section(self, params, grads, k, hidden, n_layers, loss, bi, base, y_d, B, inv_b, lr_apply=0.0):
-        """The MLP on `bi` at mini-batch sizes (fmx_mlp_section: fp32 MFMA GEMMs): forward, loss, backward.
-        -> (loss [1], dz [B], gbi [B, kp]); `grads` (flat, the layout of `params`) is filled; lr_apply != 0 also applies SGD."""
-        m = self._mlp_struct(params, k, hidden, n_layers)
+    def _mlp_big_buffers(self, m, k, hidden, n_layers, B):
         key = (k, hidden, n_layers, B)
         if getattr(self, "_mlp_ws_key", None) != key:
             nbytes = int(self.lib.fmx_mlp_section_workspace_bytes(C.byref(m), B))
@@ -251,6 +248,22 @@ class FMEngine:
             self._mlp_gbi = torch.empty((B, self.table.kp), dtype=torch.float32, device=self.device)
             self._mlp_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._mlp_ws_key = key
+
+    def mlp_forward_batch(self, params, k, hidden, n_layers, bi, base, B, want_layers):
+        """forward() of the MLP at mini-batch sizes (fmx_mlp_forward_batch) -> (logit [B], layers [L, B] or None)."""
+        m = self._mlp_struct(params, k, hidden, n_layers)
+        self._mlp_big_buffers(m, k, hidden, n_layers, B)
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        layers = torch.empty((n_layers, B), dtype=torch.float32, device=self.device) if want_layers else None
+        _lib.check(self.lib.fmx_mlp_forward_batch(C.byref(m), bi.data_ptr(), bi.stride(0), base.data_ptr(), B,
+                                                  self._mlp_ws.data_ptr(), out.data_ptr(), _ptr(layers), self._stream()))
+        return out, layers
+
+    def mlp_section(self, params, grads, k, hidden, n_layers, loss, bi, base, y_d, B, inv_b, lr_apply=0.0):
+        """The MLP on `bi` at mini-batch sizes (fmx_mlp_section: fp32 MFMA GEMMs): forward, loss, backward.
+        -> (loss [1], dz [B], gbi [B, kp]); `grads` (flat, the layout of `params`) is filled; lr_apply != 0 also applies SGD."""
+        m = self._mlp_struct(params, k, hidden, n_layers)
+        self._mlp_big_buffers(m, k, hidden, n_layers, B)
         _lib.check(self.lib.fmx_mlp_section(C.byref(m), _lib.LOSSES[loss], bi.data_ptr(), bi.stride(0), base.data_ptr(),
                                             y_d.data_ptr(), B, inv_b, self._mlp_ws.data_ptr(), None, self._mlp_dz.data_ptr(),
                                             self._mlp_gbi.data_ptr(), self.table.kp, grads.data_ptr(), lr_apply,

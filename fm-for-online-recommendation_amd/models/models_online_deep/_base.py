@@ -230,6 +230,11 @@ class OnlineFMBase(nn.Module):
                 out, layers = e.mlp_forward(self._mlp_flat, self.embedding_size, self.neuron_per_hidden_layer,
                                             self.num_hidden_layers, self._base_logit(B).contiguous(), B, self._onn)
                 return (layers[-1], layers) if self._onn else out
+            if getattr(self, "native_mlp", True):     # mini-batch sizes: the forward GEMM chain (fmx_mlp_forward_batch)
+                out, layers = e.mlp_forward_batch(self._mlp_flat, self.embedding_size, self.neuron_per_hidden_layer,
+                                                  self.num_hidden_layers, e.bi[:B], self._base_logit(B).contiguous(), B,
+                                                  self._onn)
+                return (layers[-1], layers) if self._onn else out
             acts = self._mlp(e.bi[:B, :self.embedding_size])
             base = self._base_logit(B)
             if not self._onn:

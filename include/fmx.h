@@ -252,6 +252,12 @@ int fmx_online_run_mlp(const fmx_table_t *table, const fmx_hyper_t *hyper, int32
  *   workspace: fmx_mlp_section_workspace_bytes(mlp, B) bytes, 16-byte aligned (activations, dH ping-pong, split partials)
  * Replaces: the MLP part of DeepFMAdam.fit / NFMAdam.fit at batch sizes the one-workgroup kernel does not take
  * (reference deepfm_adam.py:79-89,106-119; nfm_adam.py:78-88,105-118), i.e. nn.Linear + relu + autograd. */
+/* Forward only at mini-batch sizes (predict / forward() of the MLP classes on whole batches, e.g. the accuracy print of
+ * the pre-training loop, reference main_experiment.py:98): logit_out [B] = base + sum_j x_L[j] (may be null),
+ * layers_out [L, B] = sigmoid(base + sum_j x_l[j]) per layer (may be null; what the ONN classes' forward() returns).
+ * Same GEMMs and workspace as fmx_mlp_section. */
+int fmx_mlp_forward_batch(const fmx_mlp_t *mlp, const float *bi, int32_t ld_bi, const float *base, int32_t B, void *workspace,
+                          float *logit_out, float *layers_out, fmx_stream_t stream);
 int64_t fmx_mlp_section_workspace_bytes(const fmx_mlp_t *mlp, int32_t B);
 int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, int32_t ld_bi, const float *base,
                     const float *y, int32_t B, float inv_b, void *workspace, float *logit_out, float *dz_out,

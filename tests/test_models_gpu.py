@@ -362,3 +362,25 @@ def test_device_online_loop_equals_per_sample_loop(name):
     assert res[0][:3] == res[1][:3]
     for k in res[1][3]:
         np.testing.assert_array_equal(res[0][3][k], res[1][3][k], err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["DeepFMAdam", "NFMAdam", "DeepFMOnn", "NFMOnn"])
+def test_batch_forward_gemm_path_equals_pytorch_path(name):
+    """forward() / predict() on a whole batch (beyond the one-workgroup kernel's 16 samples) runs the MFMA forward chain;
+    with native_mlp = False the PyTorch layers: same values."""
+    z, meta = load_model_fixture(name, "criteo39s")
+    rng = np.random.default_rng(3)
+    B = 300
+    Xi = np.stack([rng.integers(0, s, size=B) for s in meta["feature_sizes"]], axis=1).reshape(B, -1, 1).tolist()
+    Xv = np.ones((B, len(meta["feature_sizes"])), dtype=np.float32).tolist()
+    outs = []
+    for native in (True, False):
+        m = build(name, meta, 1)
+        m.load_state_dict(sub(z, "A/sd0"))
+        m.native_mlp = native
+        out = m.forward(Xi, Xv)
+        outs.append([o.cpu().numpy() for o in out] if isinstance(out, tuple) else [out.cpu().numpy()])
+        pred = m.predict(Xi, Xv)
+        assert pred.shape == (B,)
+    for a, b in zip(outs[0], outs[1]):
+        assert_close(a, b, 1e-5, 2e-6 * max(np.abs(b).max(), 1.0), "forward")
