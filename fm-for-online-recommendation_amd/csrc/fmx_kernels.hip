@@ -2112,6 +2112,7 @@ static void mlp_big_forward(const fmx_mlp_t *mlp, const MlpBigWs &w, const float
     const int in = l == 0 ? k : H;
     GemmArgs g;
     g.mask = nullptr;
+    g.rowadd = nullptr;
     g.ldmask = 0;
     g.c_split_stride = 0;
     g.zero_cols_to = 0;
@@ -2164,21 +2165,15 @@ int64_t fmx_mlp_section_workspace_bytes(const fmx_mlp_t *mlp, int32_t B) {
   return (int64_t)mlp_big_carve(mlp, B, nullptr).bytes;
 }
 
-int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, int32_t ld_bi, const float *base,
-                    const float *y, int32_t B, float inv_b, void *workspace, float *logit_out, float *dz_out,
-                    float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply, float *loss_out, fmx_stream_t stream) {
-  if (!mlp || !mlp->params || !bi || !base || !y || !workspace || !dz_out || !gbi_out || !grads)
-    return fail(FMX_ERR_ARG, "fmx_mlp_section: null argument");
-  if (mlp->n_layers < 1 || mlp->n_layers > MLP_BIG_MAX_L || mlp->k < 1 || mlp->hidden < 1 || B < 1)
-    return fail(FMX_ERR_UNSUPPORTED, "fmx_mlp_section: needs 1 <= layers <= %d, k >= 1, hidden >= 1, B >= 1", MLP_BIG_MAX_L);
-  if (ld_bi < mlp->k || ld_gbi < mlp->k) return fail(FMX_ERR_SHAPE, "fmx_mlp_section: ld_bi / ld_gbi smaller than k");
-  if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "fmx_mlp_section needs a loss");
-  if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const MlpBigWs w = mlp_big_carve(mlp, B, workspace);
+// the backward of the mini-batch MLP from dH_{L-1} (already in w.dH): the dgrad chain (with `rowadd_l` [L, B] added to
+// layer l's dH before its mask when given: Hedge), dL/dbi into gbi_out when given, every layer's dW | db in one launch,
+// then the fixed-order reduction into `grads` (+ optional SGD, + the mean of w.loss_b into loss_out when given)
+static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const float *bi, int32_t ld_bi, int32_t B,
+                             const float *rowadd_l, float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply,
+                             float *loss_out, float inv_b, hipStream_t st) {
   const int L = mlp->n_layers, H = mlp->hidden, k = mlp->k;
   const size_t act = align_up((size_t)B * H * 4, 256) / 4;
-  const float *Wl[MLP_BIG_MAX_L], *bl[MLP_BIG_MAX_L];
+  const float *Wl[MLP_BIG_MAX_L];
   long long off[MLP_BIG_MAX_L];
   {
     long long o = 0;
@@ -2186,7 +2181,6 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
       const int in = l == 0 ? k : H;
       off[l] = o;
       Wl[l] = mlp->params + o;
-      bl[l] = mlp->params + o + (long long)H * in;
       o += (long long)H * in + H;
     }
   }
@@ -2194,31 +2188,12 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     GemmArgs g;
     g.bias = nullptr;
     g.mask = nullptr;
+    g.rowadd = nullptr;
     g.ldmask = 0;
     g.c_split_stride = 0;
     g.zero_cols_to = 0;
     return g;
   };
-  // ---- forward ----
-  mlp_big_forward(mlp, w, bi, ld_bi, B, st);
-  // ---- loss, dL/dlogit, dH_L ----
-  {
-    MlpLossArgs a;
-    a.H = w.acts + (size_t)(L - 1) * act;
-    a.dH = w.dH + (size_t)(L - 1) * act;
-    a.base = base;
-    a.y = y;
-    a.out = logit_out;
-    a.dz = dz_out;
-    a.loss_b = w.loss_b;
-    a.B = B;
-    a.hidden = H;
-    a.ldh = H;
-    a.loss_kind = loss_kind;
-    a.inv_b = inv_b;
-    hipLaunchKernelGGL(k_mlp_loss, dim3((B + 3) / 4), dim3(256), 0, st, a);
-  }
-  // ---- backward ----
   int splits[MLP_BIG_MAX_L] = {0};
   WgradBatch wb;
   wb.n = 0;
@@ -2228,7 +2203,7 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     float *cur = w.dH + (size_t)l * act;
     const float *prev = l == 0 ? bi : w.acts + (size_t)(l - 1) * act;
     const int ldprev = l == 0 ? ld_bi : H;
-    {  // dW_l | db_l = dH_l^T . [H_{l-1} | 1], split over the batch
+    {  // dW_l = dH_l^T . H_{l-1}, split over the batch
       GemmArgs g = base_args();
       g.A = cur;
       g.lda = H;
@@ -2257,6 +2232,7 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
       if ((in + G_BN - 1) / G_BN > wgx) wgx = (in + G_BN - 1) / G_BN;
       ++wb.n;
     }
+    if (l == 0 && !gbi_out) continue;  // nothing below the first layer wants a gradient (Hedge leaves the tables alone)
     GemmArgs g = base_args();
     g.A = cur;
     g.lda = H;
@@ -2269,11 +2245,12 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
     g.b_bytes = (unsigned)((size_t)H * g.ldb * 4);
     g.vec = (size_t)B * g.lda * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 0, 0);
-    if (l > 0) {  // dH_{l-1} = (dH_l . W_l) * (H_{l-1} > 0)
+    if (l > 0) {  // dH_{l-1} = (dH_l . W_l [+ the layer's own output gradient]) * (H_{l-1} > 0)
       g.C = w.dH + (size_t)(l - 1) * act;
       g.ldc = H;
       g.mask = prev;
       g.ldmask = H;
+      g.rowadd = rowadd_l ? rowadd_l + (size_t)(l - 1) * B : nullptr;
       launch_gemm<0, 0, EPI_MASK>(g, 1, st);
     } else {  // dL/dbi through the MLP, padding columns zeroed
       g.C = gbi_out;
@@ -2289,35 +2266,116 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
                                 (int)G_LDS_BYTES);
       raised = true;
     }
-    // grid x = the GEMM's column tiles + one slice for the bias columns (y there = blocks of 256 columns of dH_l)
+    // grid x = the GEMM's column tiles + one slice for the bias columns (y there = blocks of 64 columns of dH_l)
     hipLaunchKernelGGL(k_mlp_wgrad, dim3(wgx + 1, (H + G_BM - 1) / G_BM, wb.z_end[wb.n - 1]), dim3(256), G_LDS_BYTES, st, wb);
   }
-  // ---- partials -> flat gradients (+ optional SGD), mean loss ----
-  {
-    MlpReduceArgs a;
-    long long biggest = 0;
-    for (int l = 0; l < MLP_BIG_MAX_L; ++l) {
-      const int in = l == 0 ? k : H;
-      a.parts[l] = l < L ? w.parts[l] : nullptr;
-      a.out_dim[l] = H;
-      a.in_dim[l] = in;
-      a.ldp[l] = l < L ? w.ldp[l] : 0;
-      a.grad_off[l] = l < L ? off[l] : 0;
-      if (l < L && (long long)H * (in + 1) > biggest) biggest = (long long)H * (in + 1);
-    }
-    a.grads = grads;
-    a.params = mlp->params;
-    a.lr = lr_apply;
-    for (int l = 0; l < MLP_BIG_MAX_L; ++l) a.n_split[l] = splits[l];
-    a.n_layers = L;
-    a.loss_b = w.loss_b;
-    a.loss_out = loss_out;
-    a.B = B;
-    a.inv_b = inv_b;
-    const int bx = (int)((biggest + 255) / 256);
-    hipLaunchKernelGGL(k_mlp_reduce, dim3(bx > 256 ? 256 : bx, L), dim3(256), 0, st, a);
+  MlpReduceArgs a;
+  long long biggest = 0;
+  for (int l = 0; l < MLP_BIG_MAX_L; ++l) {
+    const int in = l == 0 ? k : H;
+    a.parts[l] = l < L ? w.parts[l] : nullptr;
+    a.out_dim[l] = H;
+    a.in_dim[l] = in;
+    a.ldp[l] = l < L ? w.ldp[l] : 0;
+    a.grad_off[l] = l < L ? off[l] : 0;
+    a.n_split[l] = splits[l];
+    if (l < L && (long long)H * (in + 1) > biggest) biggest = (long long)H * (in + 1);
   }
+  a.grads = grads;
+  a.params = mlp->params;
+  a.lr = lr_apply;
+  a.n_layers = L;
+  a.loss_b = w.loss_b;
+  a.loss_out = loss_out;
+  a.B = B;
+  a.inv_b = inv_b;
+  const int bx = (int)((biggest + 255) / 256);
+  hipLaunchKernelGGL(k_mlp_reduce, dim3(bx > 256 ? 256 : bx, L), dim3(256), 0, st, a);
+}
+
+static int mlp_big_check(const fmx_mlp_t *mlp, int32_t B, const void *workspace, const char *who) {
+  if (!mlp || !mlp->params || !workspace) return fail(FMX_ERR_ARG, "%s: null argument", who);
+  if (mlp->n_layers < 1 || mlp->n_layers > MLP_BIG_MAX_L || mlp->k < 1 || mlp->hidden < 1 || B < 1)
+    return fail(FMX_ERR_UNSUPPORTED, "%s: needs 1 <= layers <= %d, k >= 1, hidden >= 1, B >= 1", who, MLP_BIG_MAX_L);
+  if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
+  return FMX_OK;
+}
+
+int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, int32_t ld_bi, const float *base,
+                    const float *y, int32_t B, float inv_b, void *workspace, float *logit_out, float *dz_out,
+                    float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply, float *loss_out, fmx_stream_t stream) {
+  if (int rc = mlp_big_check(mlp, B, workspace, "fmx_mlp_section")) return rc;
+  if (!bi || !base || !y || !dz_out || !gbi_out || !grads) return fail(FMX_ERR_ARG, "fmx_mlp_section: null argument");
+  if (ld_bi < mlp->k || ld_gbi < mlp->k) return fail(FMX_ERR_SHAPE, "fmx_mlp_section: ld_bi / ld_gbi smaller than k");
+  if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "fmx_mlp_section needs a loss");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const MlpBigWs w = mlp_big_carve(mlp, B, workspace);
+  const int L = mlp->n_layers, H = mlp->hidden;
+  const size_t act = align_up((size_t)B * H * 4, 256) / 4;
+  mlp_big_forward(mlp, w, bi, ld_bi, B, st);
+  {  // ---- loss, dL/dlogit, dH_L ----
+    MlpLossArgs a;
+    a.H = w.acts + (size_t)(L - 1) * act;
+    a.dH = w.dH + (size_t)(L - 1) * act;
+    a.base = base;
+    a.y = y;
+    a.out = logit_out;
+    a.dz = dz_out;
+    a.loss_b = w.loss_b;
+    a.B = B;
+    a.hidden = H;
+    a.ldh = H;
+    a.loss_kind = loss_kind;
+    a.inv_b = inv_b;
+    hipLaunchKernelGGL(k_mlp_loss, dim3((B + 3) / 4), dim3(256), 0, st, a);
+  }
+  mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st);
   return check_launch("fmx_mlp_section");
+}
+
+int fmx_mlp_hedge_section(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge_s, float *alpha, const float *bi,
+                          int32_t ld_bi, const float *base, const float *y, int32_t B, void *workspace, float *grads,
+                          float *losses_out, fmx_stream_t stream) {
+  if (int rc = mlp_big_check(mlp, B, workspace, "fmx_mlp_hedge_section")) return rc;
+  if (!alpha || !bi || !base || !y || !grads) return fail(FMX_ERR_ARG, "fmx_mlp_hedge_section: null argument");
+  if (ld_bi < mlp->k) return fail(FMX_ERR_SHAPE, "fmx_mlp_hedge_section: ld_bi smaller than k");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const MlpBigWs w = mlp_big_carve(mlp, B, workspace);
+  const int L = mlp->n_layers, H = mlp->hidden;
+  const size_t act = align_up((size_t)B * H * 4, 256) / 4;
+  const float inv_b = 1.0f / (float)B;  // nn.BCELoss: the mean over the batch
+  mlp_big_forward(mlp, w, bi, ld_bi, B, st);
+  {
+    MlpHedgeLossArgs a;
+    a.acts = w.acts;
+    a.act_stride = act;
+    a.dH_top = w.dH + (size_t)(L - 1) * act;
+    a.base = base;
+    a.y = y;
+    a.alpha = alpha;
+    a.dzl = w.dzl;
+    a.loss_lb = w.loss_lb;
+    a.B = B;
+    a.hidden = H;
+    a.n_layers = L;
+    a.inv_b = inv_b;
+    hipLaunchKernelGGL(k_mlp_hedge_loss, dim3((B + 3) / 4), dim3(256), 0, st, a);
+  }
+  // hidden layers: theta -= lr * sum_i alpha_i d loss_i / d theta (one backward pass: d loss_i / d layer_j = 0 for j > i)
+  mlp_big_backward(mlp, w, bi, ld_bi, B, w.dzl, nullptr, 0, grads, lr, nullptr, inv_b, st);
+  {
+    MlpHedgeAlphaArgs a;
+    a.loss_lb = w.loss_lb;
+    a.alpha = alpha;
+    a.losses_out = losses_out;
+    a.B = B;
+    a.n_layers = L;
+    a.inv_b = inv_b;
+    a.hedge_b = hedge_b;
+    a.hedge_s = hedge_s;
+    hipLaunchKernelGGL(k_mlp_hedge_alpha, dim3(1), dim3(256), 0, st, a);
+  }
+  return check_launch("fmx_mlp_hedge_section");
 }
 
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream) {

@@ -259,6 +259,14 @@ class FMEngine:
                                                   self._mlp_ws.data_ptr(), out.data_ptr(), _ptr(layers), self._stream()))
         return out, layers
 
+    def mlp_hedge_section(self, params, grads, k, hidden, n_layers, lr, hedge_b, hedge_s, alpha, bi, base, y_d, B):
+        """Hedge backprop at mini-batch sizes (fmx_mlp_hedge_section): hidden layers and alpha updated in place."""
+        m = self._mlp_struct(params, k, hidden, n_layers)
+        self._mlp_big_buffers(m, k, hidden, n_layers, B)
+        _lib.check(self.lib.fmx_mlp_hedge_section(C.byref(m), lr, hedge_b, hedge_s, alpha.data_ptr(), bi.data_ptr(),
+                                                  bi.stride(0), base.data_ptr(), y_d.data_ptr(), B, self._mlp_ws.data_ptr(),
+                                                  grads.data_ptr(), None, self._stream()))
+
     def mlp_section(self, params, grads, k, hidden, n_layers, loss, bi, base, y_d, B, inv_b, lr_apply=0.0):
         """The MLP on `bi` at mini-batch sizes (fmx_mlp_section: fp32 MFMA GEMMs): forward, loss, backward.
         -> (loss [1], dz [B], gbi [B, kp]); `grads` (flat, the layout of `params`) is filled; lr_apply != 0 also applies SGD."""

@@ -329,6 +329,13 @@ class OnlineFMBase(nn.Module):
             e.mlp_hedge_fit(self._mlp_flat, k, self.neuron_per_hidden_layer, self.num_hidden_layers, float(self.n),
                             float(self.b.detach()), float(self.s.detach()), self.alpha, self._base_logit(B).contiguous(), y_d, B)
             return
+        if getattr(self, "native_mlp", True):    # mini-batch sizes: the same step on the MFMA GEMMs (fmx_mlp_hedge_section)
+            if getattr(self, "_mlp_gflat", None) is None:
+                self._mlp_gflat = torch.zeros_like(self._mlp_flat)
+            e.mlp_hedge_section(self._mlp_flat, self._mlp_gflat, k, self.neuron_per_hidden_layer, self.num_hidden_layers,
+                                float(self.n), float(self.b.detach()), float(self.s.detach()), self.alpha, e.bi[:B],
+                                self._base_logit(B).contiguous(), y_d, B)
+            return
         base = self._base_logit(B).detach()
         for p in self.hidden_layers.parameters():
             p.grad = None

@@ -263,6 +263,14 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
                     const float *y, int32_t B, float inv_b, void *workspace, float *logit_out, float *dz_out,
                     float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply, float *loss_out, fmx_stream_t stream);
 
+/* Hedge backprop at mini-batch sizes (the ONN classes' fit() beyond 16 samples; reference deepfm_onn.py:109-154): per
+ * layer BCELoss(sigmoid(base + sum_j x_l[j]), y), hidden layers updated by lr * sum_{i >= j} alpha_i dloss_i/dlayer_j (one
+ * backward pass on the same GEMMs; `grads` receives that gradient), then alpha_i <- max(alpha_i * hedge_b^loss_i,
+ * hedge_s / L) normalised, in place.  losses_out [L] may be null.  The tables are not touched, as in the reference. */
+int fmx_mlp_hedge_section(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge_s, float *alpha, const float *bi,
+                          int32_t ld_bi, const float *base, const float *y, int32_t B, void *workspace, float *grads,
+                          float *losses_out, fmx_stream_t stream);
+
 /* Streaming read of `bytes` (multiple of 16) with 16-byte loads; sink [1] receives a checksum so the loads stay
  * live.  Used by bench.py to measure the HBM-read ceiling on the same GPU in the same run. */
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream);

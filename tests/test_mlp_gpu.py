@@ -107,3 +107,49 @@ def test_mlp_section_rejects_bad_arguments(fmx):
     rc = lib.fmx_mlp_section(C.byref(m), fmx._lib.LOSSES["logits"], x.data_ptr(), 2, x.data_ptr(), x.data_ptr(), 4, 0.25,
                              x.data_ptr(), None, x.data_ptr(), x.data_ptr(), 4, x.data_ptr(), 0.0, None, None)
     assert rc == fmx._lib.ERR_SHAPE                                # ld_bi < k
+
+
+@pytest.mark.parametrize("B,k,kp,H,L", [(4096, 16, 16, 256, 3), (300, 10, 12, 40, 2), (50, 4, 4, 33, 4)])
+def test_mlp_hedge_section_vs_autograd(fmx, B, k, kp, H, L):
+    """fmx_mlp_hedge_section against a float64 autograd statement of Hedge backprop (reference deepfm_onn.py:109-154)."""
+    import ctypes as C
+    torch.manual_seed(B + H)
+    n_par = sum(H * (k if l == 0 else H) + H for l in range(L))
+    # small enough that sigmoid(base + sum of H activations) stays away from 1.0f: where fp32 saturates, BCELoss clamps
+    # log(1 - p) at -100 and a float64 reference (which does not saturate there) stops being a reference
+    params = (torch.randn(n_par) * min(1.0 / np.sqrt(H), 2.0 / H)).cuda()
+    bi = torch.zeros(B, kp)
+    bi[:, :k] = torch.randn(B, k) * 0.5
+    bi_d, base = bi.cuda(), (torch.randn(B) * 0.3).cuda()
+    y = (torch.rand(B) < 0.3).float().cuda()
+    alpha = torch.full((L,), 1.0 / (L + 1)).cuda()
+    lr, hb, hs = 0.05, 0.99, 0.2
+    # float64 reference
+    p = params.double().cpu()
+    Ws, bs, off = [], [], 0
+    for l in range(L):
+        i = k if l == 0 else H
+        Ws.append(p[off:off + H * i].view(H, i).clone().requires_grad_(True)); off += H * i
+        bs.append(p[off:off + H].clone().requires_grad_(True)); off += H
+    x, losses = bi_d[:, :k].double().cpu(), []
+    for W, b in zip(Ws, bs):
+        x = F.relu(x @ W.t() + b)
+        losses.append(F.binary_cross_entropy(torch.sigmoid(base.double().cpu() + x.sum(1)), y.double().cpu()))
+    a0 = alpha.double().cpu()
+    (a0 * torch.stack(losses)).sum().backward()
+    new = torch.cat([(t - lr * t.grad).reshape(-1) for pair in zip(Ws, bs) for t in pair]).detach().numpy()
+    a1 = torch.maximum(a0 * torch.pow(torch.tensor(hb, dtype=torch.float64), torch.stack(losses).detach()),
+                       torch.tensor(hs / L, dtype=torch.float64))
+    a1 = (a1 / a1.sum()).numpy()
+    lib = fmx._lib.load()
+    m = fmx._lib.Mlp(params.data_ptr(), L, k, H, 0)
+    ws = torch.empty(int(lib.fmx_mlp_section_workspace_bytes(C.byref(m), B)) // 4, device="cuda")
+    grads, lout, p0 = torch.zeros_like(params), torch.zeros(L, device="cuda"), params.clone()
+    fmx._lib.check(lib.fmx_mlp_hedge_section(C.byref(m), lr, hb, hs, alpha.data_ptr(), bi_d.data_ptr(), kp, base.data_ptr(),
+                                             y.data_ptr(), B, ws.data_ptr(), grads.data_ptr(), lout.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    close(lout.cpu().numpy(), torch.stack(losses).detach().numpy(), "per-layer losses")
+    close(alpha.cpu().numpy(), a1, "alpha")
+    close((params - p0).cpu().numpy(), new - p.numpy(), "parameter deltas", rel=5e-5)
+    np.testing.assert_array_equal((p0 - lr * grads).cpu().numpy(), params.cpu().numpy())

@@ -384,3 +384,29 @@ def test_batch_forward_gemm_path_equals_pytorch_path(name):
         assert pred.shape == (B,)
     for a, b in zip(outs[0], outs[1]):
         assert_close(a, b, 1e-5, 2e-6 * max(np.abs(b).max(), 1.0), "forward")
+
+
+@pytest.mark.parametrize("name", ["DeepFMOnn", "NFMOnn"])
+def test_hedge_mini_batch_gemm_path_equals_pytorch_path(name):
+    """The ONN classes' fit() on a batch beyond the one-workgroup kernel's 16 samples: Hedge backprop on the MFMA GEMMs
+    (fmx_mlp_hedge_section) against the PyTorch autograd form of the same step (native_mlp = False).  Plain SGD on the
+    hidden layers, so the comparison is smooth: 1e-4 on the lr-sized deltas."""
+    z, meta = load_model_fixture(name, "criteo39s")
+    rng = np.random.default_rng(8)
+    B = 200
+    Xi = np.stack([rng.integers(0, s, size=B) for s in meta["feature_sizes"]], axis=1).reshape(B, -1, 1).tolist()
+    Xv = np.ones((B, len(meta["feature_sizes"])), dtype=np.float32).tolist()
+    Y = (rng.uniform(size=B) < 0.4).astype(np.float32).tolist()
+    sd0 = sub(z, "A/sd0")
+    res = []
+    for native in (True, False):
+        m = build(name, meta, B)
+        m.load_state_dict(sd0)
+        m.native_mlp = native
+        for _ in range(3):
+            m.fit(Xi, Xv, Y)
+        res.append(sd_np(m))
+    assert_state_close(res[0], res[1], sd0, what="hedge fit: mfma vs pytorch")
+    assert not np.array_equal(res[0]["alpha"], sd0["alpha"])
+    for i in (0, 5):
+        np.testing.assert_array_equal(res[0][f"second_order_embeddings.{i}.weight"], sd0[f"second_order_embeddings.{i}.weight"])
