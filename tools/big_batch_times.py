@@ -15,4 +15,4 @@ for B in (4096, 8192, 16384):
     eng.stream(hyper, "ftrl", "logits", idx_pool, y_pool, 4, loss)
     ms = eng.stream(hyper, "ftrl", "logits", idx_pool, y_pool, 20, loss, timed=True)
     torch.cuda.synchronize()
-    print(B, {k: round(v / 20 * 1e3, 1) for k, v in zip(("sort", "fwd", "upd", "fix"), ms)}, "us")
+    print(B, {k: round(v / 20 * 1e3, 1) for k, v in zip(("sort", "fwd", "upd", "empty event pair"), ms)}, "us")

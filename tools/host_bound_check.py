@@ -1,3 +1,4 @@
+"""Host enqueue time per step of fmx_fm_stream against the time until the GPU is done (is the loop host-bound?)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "fm-for-online-recommendation_amd"))
