@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05) indices instead of uniform (secondary workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loop-only", action="store_true", help="only the timed online loop (no measuring pass, no spread pass): "
+                                                             "what tools/profile_round.sh traces for the in-loop kernel durations")
     ap.add_argument("--row-stride", type=int, default=0)
     ap.add_argument("--model", default="FMAdam", choices=sorted(PUBLISHED_ONLINE), help="--workload online: the class `value` reports")
     ap.add_argument("--workload", default="fm", choices=["fm", "deepfm", "online"],
@@ -279,17 +281,22 @@ def main():
         assert np.isfinite(losses).all(), "non-finite loss in the timed region"
         # spread of the step time: 20 separately timed chunks of 100 steps (each chunk pays one pipeline start)
         chunk_us = []
-        for _ in range(20):
+        for _ in range(20 if args.steps >= 200 and not args.loop_only else 0):
             barrier()
             tc = time.perf_counter()
             eng.stream(hyper, RULE, "logits", idx_pool, y_pool, 100, loss_buf)
             barrier()
             chunk_us.append((time.perf_counter() - tc) / 100 * 1e6)
-        # the measuring pass (fmx.h, fmx_fm_stream with kernel_ms): per step every kernel is launched 8x back to back
-        # between two HIP events on the launch stream, an empty event pair's own cost subtracted: per-launch durations
-        # for the roofline.  Not the pass timed above.
+        # the measuring pass (fmx.h, fmx_fm_stream with kernel_ms): groups of 8 steps -- one sort launch, the 8 forwards
+        # back to back, the 8 updates back to back, every launch on a different batch of the pool -- each block between
+        # two HIP events on the launch stream, an empty event pair's own cost subtracted: per-launch durations for the
+        # roofline.  Not the pass timed above.
         barrier()
-        kernel_ms = eng.stream(hyper, RULE, "logits", idx_pool, y_pool, min(args.steps, 300), loss_buf, timed=True)
+        n_meas = 0 if args.loop_only else min(8 * args.steps, 2400)
+        if n_meas:
+            if loss_buf.numel() < n_meas:
+                loss_buf = torch.zeros(n_meas, device=dev)
+            kernel_ms = eng.stream(hyper, RULE, "logits", idx_pool, y_pool, n_meas, loss_buf, timed=True)
         barrier()
     else:
         # ---- N GPUs: exact data parallelism (fmx.DataParallelFM): forward on the local slice, all-gather of the
@@ -374,15 +381,17 @@ def main():
         "final_loss": float(losses[-1]),
     }
     if kernel_ms is not None:
-        sort_ms, fwd_ms, upd_ms, pair_ms = [v / min(args.steps, 300) for v in kernel_ms]
-        out["step_us_over_100_step_chunks"] = {q: float(np.percentile(chunk_us, p)) for q, p in (("p10", 10), ("p50", 50), ("p90", 90))}
+        sort_ms, fwd_ms, upd_ms, pair_ms = [v / n_meas for v in kernel_ms]
+        if chunk_us:
+            out["step_us_over_100_step_chunks"] = {q: float(np.percentile(chunk_us, p)) for q, p in (("p10", 10), ("p50", 50), ("p90", 90))}
         ach = BYTES_K_UPDATE * BATCH / (upd_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_fm_update", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                            "algorithmic_bytes_per_launch": BYTES_K_UPDATE * BATCH, "avg_launch_ms": upd_ms,
-                           "measured": "HIP events on the launch stream around 8 back-to-back k_fm_update launches per "
-                                       "step (empty event pair subtracted), second pass over the same K batches; "
-                                       "profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same command"}
+                           "measured": "HIP events on the launch stream around groups of 8 back-to-back k_fm_update launches, "
+                                       "each on a different batch (empty event pair subtracted), in a measuring pass over "
+                                       "the same pool; profiles/ holds the rocprofv3 --kernel-trace --stats summary of the "
+                                       "same command"}
         out["kernels_ms_per_launch"] = {"k_sort_occ": sort_ms, "k_fm_forward": fwd_ms, "k_fm_update": upd_ms,
                                         "empty_event_pair": pair_ms}
     else:

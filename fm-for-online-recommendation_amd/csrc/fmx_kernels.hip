@@ -1330,7 +1330,7 @@ int check_sort_geometry(const fmx_table_t *t, int B) {
 
 // ---- launch geometry knobs (waves per workgroup), overridable from the environment for experiments ----
 struct Tune {
-  int wpb_fwd = 4, wpb_upd = 4;
+  int wpb_fwd = 2, wpb_upd = 2;  // waves per workgroup (FMX_WPB_FWD / FMX_WPB_UPD: 1, 2 or 4; a 3 x 3 sweep is flat within 1 %)
   int sort_e = 0;     // FMX_SORT_E: elements per thread of the bitonic sort (0 = default)
   int inline_fixup = 1;  // FMX_INLINE_FIXUP=0 / fmx_set_option("inline_fixup", 0): partial records are combined by a second
                          // launch (k_fm_fixup) instead of the in-launch hand-off; both give identical bits
@@ -1345,8 +1345,8 @@ Tune &tune() {
     if (const char *e = getenv("FMX_SORT_AHEAD")) x.sort_ahead = atoi(e);
     if (const char *e = getenv("FMX_INLINE_FIXUP")) x.inline_fixup = atoi(e);
     auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
-    if (!ok(x.wpb_fwd)) x.wpb_fwd = 4;
-    if (!ok(x.wpb_upd)) x.wpb_upd = 4;
+    if (!ok(x.wpb_fwd)) x.wpb_fwd = 2;
+    if (!ok(x.wpb_upd)) x.wpb_upd = 2;
     return x;
   }();
   return t;
@@ -1874,11 +1874,14 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     return rejoin(rc);
   }
 
-  // timing mode: everything on `stream`.  An event pair costs several microseconds of its own on this stack (slot 3
-  // measures exactly that: two records with nothing between), so each kernel is launched REP times back to back between
-  // two events and the pair's own cost is subtracted: per-launch figures that agree with rocprofv3's kernel trace.
-  // Repeating is harmless: the sort and the forward are idempotent, the update just applies the same step REP times.
-  const int n_ev = 5, REP = 8;
+  // measuring mode: everything on `stream`.  An event pair costs several microseconds of its own on this stack (slot 3
+  // measures exactly that: two records with nothing between), so launches are timed in groups of up to 8 steps between
+  // two events and the pair's own cost is subtracted: ONE sort launch for the group's batches (as in the production
+  // loop), then the group's forwards back to back, then its updates back to back -- every launch on a DIFFERENT batch of
+  // the pool (its own sorted list, its own S / dz / loss), so the rows come from HBM / MALL as they do in production
+  // instead of from an L2 warmed by the previous launch of the same batch.  The forwards of a group all read the table
+  // before the group's updates, so this pass is a measurement, not the online algorithm.
+  const int REP = 8, n_ev = 5;
   hipStream_t user_t = st;
   Side *sdt = (st == nullptr) ? side_for_current_device() : nullptr;  // same detour off the legacy stream as above
   if (sdt) {
@@ -1886,21 +1889,41 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     st = sdt->main;
     (void)hipStreamWaitEvent(st, sdt->user_fork, 0);
   }
-  hipEvent_t *ev = new hipEvent_t[(size_t)n_steps * n_ev];
-  for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventCreate(&ev[i]);
-  for (int s = 0; s < n_steps && rc == FMX_OK; ++s) {
-    const int j = s % n_pool;
-    const int32_t *idx = idx_pool + (size_t)j * B * F;
-    const float *y = y_pool + (size_t)j * B;
-    hipEvent_t *e = ev + (size_t)s * n_ev;
+  const int n_groups = (n_steps + REP - 1) / REP;
+  const size_t region = align_up((size_t)B * table->kp + 2 * (size_t)B, 64);  // floats: S | dz | loss of one batch
+  float *tmp = nullptr;
+  if (n_groups > 0 && hipMalloc(&tmp, REP * region * sizeof(float)) != hipSuccess) return fail(FMX_ERR_LAUNCH, "hipMalloc (measuring mode)");
+  hipEvent_t *ev = new hipEvent_t[(size_t)n_groups * n_ev];
+  for (int i = 0; i < n_groups * n_ev; ++i) (void)hipEventCreate(&ev[i]);
+  for (int g = 0; g < n_groups && rc == FMX_OK; ++g) {
+    const int first = g * REP, n = (n_steps - first) < REP ? (n_steps - first) : REP;
+    hipEvent_t *e = ev + (size_t)g * n_ev;
     (void)hipEventRecord(e[0], st);
-    for (int r = 0; r < REP && rc == FMX_OK; ++r) rc = sort_impl(table, idx, B, w.sorted, fwd->error, st);
+    {
+      SortBatch mb;
+      mb.n_pool = n_pool;
+      mb.first = first % n_pool;
+      mb.n_batches = n;
+      mb.pool_stride = (int64_t)B * (int64_t)F;
+      mb.sorted_stride = (int64_t)w.sorted_stride;
+      rc = sort_impl(table, idx_pool, B, w.sorted, fwd->error, st, &mb);
+    }
     (void)hipEventRecord(e[1], st);
-    for (int r = 0; r < REP && rc == FMX_OK; ++r) rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
+    for (int r = 0; r < n && rc == FMX_OK; ++r) {
+      const int j = (first + r) % n_pool;
+      fmx_fwd_out_t fr = *fwd;
+      fr.S = tmp + (size_t)r * region;
+      fr.dz = fr.S + (size_t)B * table->kp;
+      fr.loss = fr.dz + B;
+      fr.sample_ld = 0;
+      rc = forward_impl(table, hyper, idx_pool + (size_t)j * B * F, nullptr, y_pool + (size_t)j * B, B, loss_kind, inv_b, &fr, st);
+    }
     (void)hipEventRecord(e[2], st);
-    for (int r = 0; r < REP && rc == FMX_OK; ++r)
-      rc = update_impl(table, hyper, rule, w, w.sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                       loss_out ? loss_out + s : nullptr, st, nullptr, fwd->sample_ld, fwd->error);
+    for (int r = 0; r < n && rc == FMX_OK; ++r) {
+      const float *S = tmp + (size_t)r * region, *dz = S + (size_t)B * table->kp;
+      rc = update_impl(table, hyper, rule, w, w.sorted + (size_t)r * w.sorted_stride, nullptr, S, dz, dz, nullptr, B, dz + B, inv_b,
+                       loss_out ? loss_out + first + r : nullptr, st, nullptr, 0, fwd->error);
+    }
     (void)hipEventRecord(e[3], st);
     (void)hipEventRecord(e[4], st);
   }
@@ -1910,21 +1933,27 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     (void)hipStreamWaitEvent(user_t, sdt->user_join, 0);
   }
   for (int k = 0; k < 4; ++k) kernel_ms[k] = 0.f;
-  if (rc == FMX_OK) {
-    for (int s = 0; s < n_steps; ++s) {
-      hipEvent_t *e = ev + (size_t)s * n_ev;
-      float pair = 0.f;
+  if (rc == FMX_OK && n_groups > 0) {
+    double t_sort = 0, t_fwd = 0, t_upd = 0, t_pair = 0;
+    for (int g = 0; g < n_groups; ++g) {
+      hipEvent_t *e = ev + (size_t)g * n_ev;
+      float pair = 0.f, ms[3] = {0.f, 0.f, 0.f};
       (void)hipEventElapsedTime(&pair, e[3], e[4]);
-      kernel_ms[3] += pair;
-      for (int k = 0; k < 3; ++k) {
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e[k], e[k + 1]);
-        kernel_ms[k] += fmaxf(ms - pair, 0.f) / REP;
-      }
+      for (int k = 0; k < 3; ++k) (void)hipEventElapsedTime(&ms[k], e[k], e[k + 1]);
+      t_pair += pair;
+      t_sort += fmaxf(ms[0] - pair, 0.f);
+      t_fwd += fmaxf(ms[1] - pair, 0.f);
+      t_upd += fmaxf(ms[2] - pair, 0.f);
     }
+    // returned as (average per launch) x n_steps, so that dividing by n_steps gives the per-launch averages
+    kernel_ms[0] = (float)(t_sort / n_groups * n_steps);  // one launch per group of up to 8 batches, as in production
+    kernel_ms[1] = (float)t_fwd;                           // n_steps forward launches in all
+    kernel_ms[2] = (float)t_upd;
+    kernel_ms[3] = (float)(t_pair / n_groups * n_steps);
   }
-  for (int i = 0; i < n_steps * n_ev; ++i) (void)hipEventDestroy(ev[i]);
+  for (int i = 0; i < n_groups * n_ev; ++i) (void)hipEventDestroy(ev[i]);
   delete[] ev;
+  if (tmp) (void)hipFree(tmp);
   return rc;
 }
 

@@ -180,11 +180,14 @@ int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
 /* The online loop over a device-resident stream of mini-batches: step s uses batch (s mod n_pool).
  * Replaces: the driver loops reference main_experiment.py:92-105 (pre-training) and fm_adam.py:97-99
  * (run_experiment), batched.  idx_pool [n_pool, B, F], y_pool [n_pool, B]; loss_out [n_steps] or null.
- * kernel_ms (HOST pointer, [4]) or null: the measuring mode.  Everything runs on `stream`; per step each kernel is launched
- * 8 times back to back between two HIP events (the sort and the forward are idempotent; the update applies the step 8 times,
- * so the table is NOT the production run's), and after a stream synchronise the summed PER-LAUNCH durations in milliseconds
- * of {sort, forward, update (both launches of it when inline_fixup = 0)} come back in [0..2], each with the cost of an
- * empty event pair -- returned, summed, in [3] -- subtracted. */
+ * kernel_ms (HOST pointer, [4]) or null: the measuring mode.  Everything runs on `stream` in groups of up to 8 steps: ONE
+ * sort launch for the group's batches (as in production), the group's forwards back to back, then its updates back to
+ * back, each block between two HIP events, every launch on a different batch of the pool (own sorted list, own
+ * S / dz / loss in a temporary buffer) so that rows come from HBM / MALL as in production.  The forwards of a group all
+ * read the table before the group's updates: the table is NOT the production run's.  After a stream synchronise
+ * kernel_ms[0..2] = n_steps x the average per-launch milliseconds of {sort (up to 8 batches per launch), forward,
+ * update (both launches of it when inline_fixup = 0)}, each with the cost of an empty event pair -- [3], same scaling --
+ * subtracted. */
 int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
                   const int32_t *idx_pool, const float *y_pool, int32_t n_pool, int32_t B, float inv_b,
                   int32_t n_steps, void *workspace, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,

@@ -35,6 +35,9 @@ if os.path.exists(bench):
 stats = find("stats", "*kernel_stats.csv")
 if stats:
     put(f"{tag}_kernel_stats.csv", src=stats)
+loop = find("loop", "*kernel_stats.csv")
+if loop:
+    put(f"{tag}_loop_kernel_stats.csv", src=loop)
 
 
 def short(name):
