@@ -1015,10 +1015,11 @@ __global__ __launch_bounds__(64) void k_fm_online(OnlineArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row stores are acknowledged before the next sample's loads
   }
+  const bool any_bad = __ballot(bad) != 0ull;  // an out-of-range index seen by any lane group
   if (lane == 0) {
     a.bias[0] = b0;
     if (LAYOUT == FMX_LAYOUT_FTRL) a.bias[1] = b1;
-    if (bad && a.error) *a.error = 1;
+    if (any_bad && a.error) *a.error = 1;
   }
 }
 
@@ -1962,15 +1963,15 @@ int fmx_fm_online_run(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_
                       int32_t *error, fmx_stream_t stream) {
   if (int rc = check_table(table)) return rc;
   if (int rc = check_rule(table, rule)) return rc;
-  if (!hyper || !idx || !y || !pred_out) return fail(FMX_ERR_ARG, "fmx_fm_online_run: null argument");
   if (N < 0) return fail(FMX_ERR_ARG, "fmx_fm_online_run: N must be >= 0");
+  if (N == 0) return FMX_OK;  // an empty stream (its buffers may be null)
+  if (!hyper || !idx || !y || !pred_out) return fail(FMX_ERR_ARG, "fmx_fm_online_run: null argument");
   if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "fit needs a loss");
   const int lpr = lpr_of(table->kp), slots = WAVE / lpr;
   const int np = (table->n_fields + slots - 1) / slots;
   if (np > 4)
     return fail(FMX_ERR_UNSUPPORTED, "fmx_fm_online_run: %d fields at kp = %d exceed the %d rows one wavefront holds", table->n_fields,
                 table->kp, 4 * slots);
-  if (N == 0) return FMX_OK;
   OnlineArgs a;
   a.rows = table->rows;
   a.foff = table->field_offsets;

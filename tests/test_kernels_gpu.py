@@ -573,3 +573,31 @@ def test_online_run_equals_single_sample_steps(fmx, rule, k, real_x):
     np.testing.assert_array_equal(t1.bias.cpu().numpy(), t2.bias.cpu().numpy())
     np.testing.assert_array_equal(loss_b.cpu().numpy(), np.asarray(losses2, dtype=np.float32))
     assert pred.cpu().numpy().astype(bool).tolist() == preds2
+
+
+def test_online_run_edge_cases(fmx):
+    """N = 0 is a no-op; more fields than one wavefront holds is refused; an out-of-range index raises the error flag and
+    contributes nothing; the loss-free call works."""
+    k = 16
+    pr = make_problem(MIXED_SIZES, k, 8, seed=2)
+    t = weights_table(fmx, MIXED_SIZES, k, pr)
+    eng = fmx.FMEngine(t, max_batch=8)
+    hyp = fmx.Hyper(**HYP)
+    idx_d, _, y_d = eng.to_device(pr["idx"], None, pr["y"])
+    before = t.rows.clone()
+    pred, loss = eng.online_run(hyp, "sgd", "logits", idx_d[:0], None, y_d[:0])
+    torch.cuda.synchronize()
+    assert pred.numel() == 0 and loss is None and torch.equal(before, t.rows)
+    bad = idx_d.clone()
+    bad[3, 2] = MIXED_SIZES[2] + 5
+    eng.online_run(hyp, "sgd", "logits", bad, None, y_d)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        eng.check_error_flag()
+    wide = fmx.FlatTable([7] * 70, k)                                  # 70 fields > 64 at kp = 16
+    e2 = fmx.FMEngine(wide, max_batch=4)
+    assert not e2.online_run_fits(70, wide.kp)
+    idx_w = torch.zeros((2, 70), dtype=torch.int32, device="cuda")
+    with pytest.raises(fmx._lib.FmxError) as ei:
+        e2.online_run(hyp, "sgd", "logits", idx_w, None, torch.zeros(2, device="cuda"))
+    assert ei.value.code == fmx._lib.ERR_UNSUPPORTED
