@@ -89,7 +89,16 @@ def cpu_baseline(idx_pool, y_pool, sizes, seconds=12.0):
     cores = min(cores, 32)                              # the update has 39-way parallelism; a one-GPU box's CPU share is 16
     run(cores, 1.0, 8)                                  # thread pool warm-up
     nm, dtm = run(cores, seconds / 2, 2048)
-    return dict(value=nm * B / dtm, unit="samples/s", cores=cores, kind="port",
+    dense = None
+    try:                                                # what the reference's own formulation costs
+        from oracle import dense_mode
+        rate, thr = dense_mode.time_dense_steps(sizes, K_EMB, idx_pool[:4], y_pool[:4], n_steps=3, lr=HYPER["lr"], threads=cores)
+        dense = {"value": rate, "unit": "samples/s", "cores": thr,
+                 "sample": "3 steps of B=4096 through oracle/dense_mode.py: 78 nn.Embedding tables, dense gradients and a fresh "
+                           "torch.optim.Adam over all 11 M parameters per step (the reference's formulation, its sign rule)"}
+    except Exception as exc:                            # informational only
+        dense = {"error": repr(exc)}
+    return dict(reference_faithful_dense=dense, value=nm * B / dtm, unit="samples/s", cores=cores, kind="port",
                 sample=f"{nm} steps of B={B} of the same synthetic stream through oracle/fm_oracle.c fmo_fm_step_mt (plain C, "
                        f"gcc -O2 -fopenmp, {cores} threads: forward over samples, update over the 39 fields)",
                 one_thread={"value": n1 * B / dt1, "unit": "samples/s", "cores": 1,

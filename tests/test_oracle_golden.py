@@ -221,3 +221,34 @@ def test_c_oracle_openmp_form_gives_the_same_bits(rule):
         assert la == lb
     for kk in a:
         np.testing.assert_array_equal(np.asarray(a[kk]), np.asarray(b[kk]))
+
+
+def test_dense_reference_mode_equals_oracle_step():
+    """oracle/dense_mode.py (bench.py's reference-faithful dense CPU timing: 2 x F nn.Embedding tables, dense gradients, a
+    fresh torch.optim.Adam per step) takes the same step as the golden-pinned row-sparse oracle.  Entries whose gradient
+    is of the order of Adam's eps (1e-8) are sign-like sensitive and excluded by magnitude of the reference step."""
+    import torch
+    from oracle import dense_mode
+    torch.manual_seed(0)
+    sizes, k, B, lr = [7, 5, 11, 3], 4, 8, 0.01
+    m = dense_mode.DenseFM(sizes, k, lr)
+    sd = {"bias": m.bias.detach().numpy().copy(), "n": np.float32(lr)}
+    for i in range(len(sizes)):
+        sd[f"first_order_embeddings.{i}.weight"] = m.first[i].weight.detach().numpy().copy()
+        sd[f"second_order_embeddings.{i}.weight"] = m.second[i].weight.detach().numpy().copy()
+    rng = np.random.default_rng(1)
+    Xi = np.stack([rng.integers(0, s, size=B) for s in sizes], axis=1)
+    Xv = np.ones_like(Xi, dtype=np.float32)
+    Y = (rng.uniform(size=B) < 0.5).astype(np.float32)
+    om = orc.OracleModel("FMAdam", {kk: v.copy() for kk, v in sd.items()})
+    l_ref = om.update_embedding(Xi.reshape(B, -1, 1), Xv, Y)
+    l_dense = m.step(torch.from_numpy(Xi), torch.from_numpy(Xv), torch.from_numpy(Y))
+    assert abs(l_dense - float(l_ref)) <= 1e-6 * abs(float(l_ref))
+    ref = om.state_dict()
+    for i in range(len(sizes)):
+        for name, got in ((f"first_order_embeddings.{i}.weight", m.first[i].weight), (f"second_order_embeddings.{i}.weight", m.second[i].weight)):
+            a, b, p = got.detach().numpy().astype(np.float64), ref[name].astype(np.float64), sd[name].astype(np.float64)
+            firm = np.abs(b - p) > 0.9 * lr          # |g| >> eps: the step is lr * sign(g)
+            np.testing.assert_allclose(a[firm], b[firm], rtol=0, atol=1e-6)
+            untouched = (b == p)
+            np.testing.assert_array_equal(a[untouched], p[untouched])
