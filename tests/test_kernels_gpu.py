@@ -429,10 +429,12 @@ def test_data_parallel_wrapper_single_rank_equals_step(fmx):
     np.testing.assert_array_equal(t1.bias.cpu().numpy(), t2.bias.cpu().numpy())
 
 
-@pytest.mark.parametrize("F,k,B", [(1, 4, 65), (2, 8, 129), (70, 16, 257), (5, 24, 300), (3, 64, 200), (39, 7, 64), (17, 16, 8192)])
+@pytest.mark.parametrize("F,k,B", [(1, 4, 65), (2, 8, 129), (70, 16, 257), (5, 24, 300), (3, 64, 200), (39, 7, 64), (17, 16, 8192),
+                                   (9, 16, 16384), (5, 8, 32768)])
 def test_step_shape_sweep(fmx, F, k, B):
     """Template paths the Criteo shape does not reach: 1 / 2 / 8 / 16 lanes per row, the generic field loop (F > 64),
-    batch sizes straddling the 64-entry tiles, and the largest single-buffer sort width."""
+    batch sizes straddling the 64-entry tiles, and the widest sorts (16 and 32 composites per thread; 32,768 is the
+    maximum batch of one step)."""
     rng = np.random.default_rng(F * 1000 + k)
     sizes = [int(s) for s in rng.choice([1, 2, 3, 5, 40, 700, 20000], size=F)]
     for rule in ("sgd", "ftrl"):
