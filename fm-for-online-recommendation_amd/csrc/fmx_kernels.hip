@@ -1119,7 +1119,8 @@ __device__ __forceinline__ float *mlp_w(const MlpArgs &a, int l) {
   return a.params + off;
 }
 
-__global__ __launch_bounds__(256) void k_mlp_small(MlpArgs a) {
+// the body of k_mlp_small; also called once per sample by k_online_mlp (every pointer may then point into LDS)
+__device__ void mlp_small_body(const MlpArgs &a) {
   __shared__ float acts[(MLP_MAX_L + 1) * MLP_MAX_B * MLP_MAX_W];  // x_0 .. x_L, [l][b][j]
   __shared__ float dA[MLP_MAX_B * MLP_MAX_W], dB[MLP_MAX_B * MLP_MAX_W];  // d x_l (ping-pong); dA is reused as d pre
   __shared__ float dout[MLP_MAX_L * MLP_MAX_B];  // d loss / d (out_l[b]) per layer (HEDGE) or for the last layer (FIT)
@@ -1259,6 +1260,182 @@ __global__ __launch_bounds__(256) void k_mlp_small(MlpArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_mlp_small(MlpArgs a) { mlp_small_body(a); }
+
+// ------------------------------------------------------------------------------------------------------------
+// k_online_mlp: the online predict-then-fit loop of the classes with an MLP, one workgroup walking the stream
+// ------------------------------------------------------------------------------------------------------------
+// Per sample: wave 0 gathers the sample's rows (sc1 loads: the previous sample may have written them) and evaluates the
+// FM part exactly as k_fm_forward does; the whole workgroup runs the MLP step of k_mlp_small (fit or Hedge) on parameters
+// that live in LDS for the length of the stream; wave 0 then applies the table update of k_fm_update at B = 1 from the
+// rows it still holds (not with Hedge, which leaves the tables alone).  Same arithmetic as the per-sample launches
+// (forward, k_mlp_small, sort, update), so the parameters end bit-identical; no launch gaps, no host in the loop.
+struct OnlineMlpArgs {
+  float *rows;
+  const int64_t *foff;
+  float *bias;
+  const int32_t *idx;
+  const float *xv;
+  const float *y;
+  float *pred;      // [N] what forward() returns for the sample, before its update
+  int32_t *error;
+  float *params;    // global: copied into LDS, written back at the end
+  float *alpha;     // Hedge: global [L], same treatment
+  fmx_hyper_t h;    // alpha already inverted (table rule); lr / eps also drive the MLP rule
+  float hedge_b, hedge_s;
+  int32_t N, F, stride, zoff, n_params;
+  int32_t k, hidden, n_layers, hedge, fm_term, rule, loss_kind;
+};
+
+template <int LPR, int LAYOUT, int RULE>
+__global__ __launch_bounds__(256) void k_online_mlp(OnlineMlpArgs a) {
+  constexpr int SLOTS = WAVE / LPR, NP = 4;
+  extern __shared__ float p_lds[];  // [n_params] the MLP's parameters
+  __shared__ float bi_lds[MLP_MAX_W], gbi_lds[MLP_MAX_W], alpha_lds[MLP_MAX_L];
+  __shared__ float base_lds, dz_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = lane / LPR, q = lane % LPR;
+  const int kp = LPR * 4;
+  for (int i = tid; i < a.n_params; i += blockDim.x) p_lds[i] = a.params[i];
+  if (a.hedge && tid < a.n_layers) alpha_lds[tid] = a.alpha[tid];
+  float b0 = a.bias[0], b1 = LAYOUT == FMX_LAYOUT_FTRL ? a.bias[1] : 0.f;
+  int64_t lo[NP];
+  uint32_t vocab[NP];
+  bool live[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int f = p * SLOTS + slot;
+    live[p] = f < a.F;
+    lo[p] = live[p] ? a.foff[f] : 0;
+    vocab[p] = live[p] ? (uint32_t)(a.foff[f + 1] - lo[p]) : 0u;
+  }
+  bool bad = false;
+  __syncthreads();
+  for (int i = 0; i < a.N; ++i) {
+    uint32_t li[NP];
+    float x[NP];
+    RowRegs row[NP];
+    bool ok[NP];
+    float4 S = splat(0.f);
+    if (wave == 0) {
+      // ---- the FM part: the arithmetic of k_fm_forward ----
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        li[p] = 0;
+        x[p] = 1.f;
+        if (live[p]) {
+          const size_t o = (size_t)i * a.F + p * SLOTS + slot;
+          li[p] = (uint32_t)a.idx[o];
+          if (a.xv) x[p] = a.xv[o];
+        }
+        ok[p] = live[p] && li[p] < vocab[p];
+        row[p].v = splat(0.f);
+        row[p].z = splat(0.f);
+        row[p].n = splat(0.f);
+        row[p].fo = splat(0.f);
+        if (ok[p]) row[p] = load_row_sc1<LAYOUT>(a.rows + (size_t)(lo[p] + li[p]) * a.stride, q, kp, a.zoff);
+        else if (live[p]) bad = true;
+      }
+      float4 s = splat(0.f), ss = splat(0.f);
+      float fo = 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (ok[p]) {
+          const float4 e = x[p] * row[p].v;
+          s = s + e;
+          ss = ss + e * e;
+          fo += row[p].fo.x * x[p];
+        }
+      }
+#define FMX_BFLY(M)                               \
+  if (LPR <= M) {                                 \
+    s = s + xor_lane_f4<M>(s, lane);              \
+    ss = ss + xor_lane_f4<M>(ss, lane);           \
+    fo += xor_lane_f<M>(fo, lane);                \
+  }
+      FMX_BFLY(1) FMX_BFLY(2) FMX_BFLY(4) FMX_BFLY(8) FMX_BFLY(16) FMX_BFLY(32)
+#undef FMX_BFLY
+      S = s;
+      const float4 bi = 0.5f * (s * s - ss);
+      float sbi = (bi.x + bi.y) + (bi.z + bi.w);
+#pragma unroll
+      for (int m = 1; m < LPR; m <<= 1) sbi += __shfl_xor(sbi, m);
+      fo = __shfl(fo, 0);
+      const float bias_w = LAYOUT == FMX_LAYOUT_WEIGHTS ? b0 : ftrl_w(b0, b1, a.h);
+      if (lane < LPR) {
+        bi_lds[4 * q] = bi.x;
+        bi_lds[4 * q + 1] = bi.y;
+        bi_lds[4 * q + 2] = bi.z;
+        bi_lds[4 * q + 3] = bi.w;
+      }
+      if (lane == 0) base_lds = a.fm_term ? fo + sbi + bias_w : fo + bias_w;
+    }
+    __syncthreads();
+    // ---- the MLP step of k_mlp_small on LDS-resident parameters ----
+    MlpArgs m{};
+    m.params = p_lds;
+    m.bi = bi_lds;
+    m.base = &base_lds;
+    m.y = a.y + i;
+    m.pred_out = a.pred + i;
+    m.h = a.h;
+    m.inv_b = 1.0f;
+    m.B = 1;
+    m.k = a.k;
+    m.kp = kp;
+    m.hidden = a.hidden;
+    m.n_layers = a.n_layers;
+    if (a.hedge) {
+      m.alpha = alpha_lds;
+      m.hedge_b = a.hedge_b;
+      m.hedge_s = a.hedge_s;
+      m.mode = MLP_MODE_HEDGE;
+    } else {
+      m.dz_out = &dz_lds;
+      m.gbi_out = gbi_lds;
+      m.mode = MLP_MODE_FIT;
+      m.rule = a.rule;
+      m.loss_kind = a.loss_kind;
+    }
+    mlp_small_body(m);
+    __syncthreads();
+    if (wave == 0 && !a.hedge) {
+      // ---- the table update of k_fm_update at B = 1: every row is a run of one occurrence, G = dz [+ dL/dbi] ----
+      const float dz = dz_lds;
+      const float4 g4 = {gbi_lds[4 * q], gbi_lds[4 * q + 1], gbi_lds[4 * q + 2], gbi_lds[4 * q + 3]};
+      const float4 G = splat(a.fm_term ? dz : 0.f) + g4;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (ok[p]) {
+          const float4 xG = x[p] * G;
+          update_row<LAYOUT, RULE>(a.rows + (size_t)(lo[p] + li[p]) * a.stride, q, kp, a.zoff, row[p], xG * S, x[p] * xG, x[p] * dz,
+                                   a.h);
+        }
+      }
+      if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
+        b0 = apply_rule<RULE>(b0, dz, a.h);
+      } else {
+        const float w = ftrl_w(b0, b1, a.h);
+        ftrl_upd(b0, b1, w, dz, a.h);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row stores are acknowledged before the next sample's loads
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < a.n_params; i += blockDim.x) a.params[i] = p_lds[i];
+  if (a.hedge && tid < a.n_layers) a.alpha[tid] = alpha_lds[tid];
+  if (wave == 0) {
+    const bool any_bad = __ballot(bad) != 0ull;
+    if (lane == 0) {
+      if (!a.hedge) {
+        a.bias[0] = b0;
+        if (LAYOUT == FMX_LAYOUT_FTRL) a.bias[1] = b1;
+      }
+      if (any_bad && a.error) *a.error = 1;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_stream_read: HBM-read ceiling probe
 // ------------------------------------------------------------------------------------------------------------
@@ -1335,6 +1512,7 @@ struct Tune {
   int sort_e = 0;     // FMX_SORT_E: elements per thread of the bitonic sort (0 = default)
   int inline_fixup = 1;  // FMX_INLINE_FIXUP=0 / fmx_set_option("inline_fixup", 0): partial records are combined by a second
                          // launch (k_fm_fixup) instead of the in-launch hand-off; both give identical bits
+  int online_persistent = 1;  // FMX_ONLINE_PERSISTENT=0 / fmx_set_option("online_persistent", 0): fmx_online_run_mlp as per-sample launches
   int sort_ahead = 8;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..8)
 };
 Tune &tune() {
@@ -1344,6 +1522,7 @@ Tune &tune() {
     if (const char *e = getenv("FMX_WPB_UPD")) x.wpb_upd = atoi(e);
     if (const char *e = getenv("FMX_SORT_E")) x.sort_e = atoi(e);
     if (const char *e = getenv("FMX_SORT_AHEAD")) x.sort_ahead = atoi(e);
+    if (const char *e = getenv("FMX_ONLINE_PERSISTENT")) x.online_persistent = atoi(e);
     if (const char *e = getenv("FMX_INLINE_FIXUP")) x.inline_fixup = atoi(e);
     auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
     if (!ok(x.wpb_fwd)) x.wpb_fwd = 2;
@@ -1669,6 +1848,26 @@ void launch_online(const OnlineArgs &a, int rule, int np, hipStream_t st) {
   }
 }
 
+constexpr int ONLINE_MLP_MAX_PARAMS = 8192;  // floats of MLP parameters kept in LDS by k_online_mlp
+
+template <int LPR, int LAYOUT, int RULE>
+void launch_online_mlp_k(const OnlineMlpArgs &a, hipStream_t st) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_online_mlp<LPR, LAYOUT, RULE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, ONLINE_MLP_MAX_PARAMS * 4);
+    raised = true;
+  }
+  hipLaunchKernelGGL((k_online_mlp<LPR, LAYOUT, RULE>), dim3(1), dim3(256), (size_t)a.n_params * 4, st, a);
+}
+
+template <int LPR>
+void launch_online_mlp(const OnlineMlpArgs &a, int layout, int rule, hipStream_t st) {
+  if (layout == FMX_LAYOUT_FTRL) launch_online_mlp_k<LPR, FMX_LAYOUT_FTRL, FMX_RULE_FTRL>(a, st);  // Hedge only: tables are read
+  else if (rule == FMX_RULE_SGD) launch_online_mlp_k<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD>(a, st);
+  else launch_online_mlp_k<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM>(a, st);
+}
+
 int check_forward_args(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *y, int32_t B,
                        int32_t loss_kind, const fmx_fwd_out_t *out) {
   if (int rc = check_table(table)) return rc;
@@ -1712,6 +1911,7 @@ int fmx_set_option(const char *name, int value) {
   int *slot = nullptr;
   if (!strcmp(name, "inline_fixup")) slot = &t.inline_fixup;
   else if (!strcmp(name, "sort_ahead")) slot = &t.sort_ahead;
+  else if (!strcmp(name, "online_persistent")) slot = &t.online_persistent;
   else return fail(FMX_ERR_ARG, "fmx_set_option: unknown option '%s'", name);
   const int old = *slot;
   *slot = value;
@@ -2037,6 +2237,50 @@ int fmx_online_run_mlp(const fmx_table_t *table, const fmx_hyper_t *hyper, int32
   }
   if (N < 0) return fail(FMX_ERR_ARG, "N must be >= 0");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  {  // one workgroup walks the stream when the network fits in LDS and the fields fit one wavefront (k_online_mlp)
+    long long n_params = 0;
+    for (int l = 0; l < mlp->n_layers; ++l) n_params += (long long)mlp->hidden * (l == 0 ? mlp->k : mlp->hidden) + mlp->hidden;
+    const int lpr = lpr_of(table->kp), slots = WAVE / lpr;
+    const bool tables_ok = hedge || table->layout == FMX_LAYOUT_WEIGHTS;
+    if (tune().online_persistent && n_params <= ONLINE_MLP_MAX_PARAMS && table->n_fields <= 4 * slots && tables_ok &&
+        mlp->hidden <= MLP_MAX_W && mlp->n_layers <= MLP_MAX_L && mlp->k <= MLP_MAX_W - 1 && N > 0) {
+      OnlineMlpArgs a;
+      a.rows = table->rows;
+      a.foff = table->field_offsets;
+      a.bias = table->bias;
+      a.idx = idx;
+      a.xv = xv;
+      a.y = y;
+      a.pred = pred_out;
+      a.error = fwd->error;
+      a.params = mlp->params;
+      a.alpha = alpha;
+      a.h = *hyper;
+      a.h.alpha = 1.0f / hyper->alpha;
+      a.hedge_b = hedge_b;
+      a.hedge_s = hedge_s;
+      a.N = N;
+      a.F = table->n_fields;
+      a.stride = table->row_stride;
+      a.zoff = table->z_offset;
+      a.n_params = (int32_t)n_params;
+      a.k = mlp->k;
+      a.hidden = mlp->hidden;
+      a.n_layers = mlp->n_layers;
+      a.hedge = hedge;
+      a.fm_term = fm_term;
+      a.rule = rule;
+      a.loss_kind = loss_kind;
+      switch (lpr) {
+        case 1: launch_online_mlp<1>(a, table->layout, rule, st); break;
+        case 2: launch_online_mlp<2>(a, table->layout, rule, st); break;
+        case 4: launch_online_mlp<4>(a, table->layout, rule, st); break;
+        case 8: launch_online_mlp<8>(a, table->layout, rule, st); break;
+        default: launch_online_mlp<16>(a, table->layout, rule, st); break;
+      }
+      return check_launch("k_online_mlp");
+    }
+  }
   const Workspace w = carve(table, 1, workspace);
   const size_t F = (size_t)table->n_fields;
   fmx_fwd_out_t f1 = *fwd;  // one sample: dense outputs
