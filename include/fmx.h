@@ -236,8 +236,10 @@ int fmx_mlp_hedge_fit(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge
  * forward (pred_out[i] = what forward() returns: the logit for the Adam classes, sigmoid of the last layer's logit for
  * the ONN classes), then fit on that sample -- hedge = 0: fmx_mlp_fit + the table update (DeepFMAdam / NFMAdam.fit),
  * hedge = 1: fmx_mlp_hedge_fit (the ONN classes: hidden layers and alpha only).  fm_term: the FM logit is part of the
- * network's input logit (DeepFM) or only the first-order sum and the bias (NFM).  The launches of all samples are queued
- * without any host synchronisation (2 per sample with Hedge, 4 otherwise).  workspace: fmx_workspace_bytes(table, 1);
+ * network's input logit (DeepFM) or only the first-order sum and the bias (NFM).  One workgroup walks the stream with the
+ * network's parameters in LDS (k_online_mlp) when they are at most 8,192 floats, the fields fit one wavefront and the tables
+ * are not FTRL tables under a fit step; otherwise the launches of all samples are queued without any host synchronisation
+ * (2 per sample with Hedge, 4 otherwise).  Either way the parameters end bit-identical to per-sample calls.  workspace: fmx_workspace_bytes(table, 1);
  * fwd: S, bi, sfirst, logit of at least one sample; scratch: >= kp + 8 floats, 16-byte aligned.
  * Replaces: the loop body of run_experiment (reference deepfm_adam.py:128-130, deepfm_onn.py:178-180, ...). */
 int fmx_online_run_mlp(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
