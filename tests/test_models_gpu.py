@@ -410,3 +410,30 @@ def test_hedge_mini_batch_gemm_path_equals_pytorch_path(name):
     assert not np.array_equal(res[0]["alpha"], sd0["alpha"])
     for i in (0, 5):
         np.testing.assert_array_equal(res[0][f"second_order_embeddings.{i}.weight"], sd0[f"second_order_embeddings.{i}.weight"])
+
+
+def test_device_online_loop_with_ftrl_tables_under_hedge():
+    """An ONN class over an FTRL-layout table (update_rule="ftrl" for its update_embedding): Hedge's run_experiment loop on
+    the device reads the cached weights of that layout.  One workgroup walking the stream == the per-sample launches, bit
+    for bit; the per-sample Python loop derives NFM's bias weight with torch ops instead of the kernels' 1-ulp rcp / sqrt,
+    so it is compared at 1e-5."""
+    import fmx
+    lib = fmx._lib.load()
+    z, meta = load_model_fixture("NFMOnn", "criteo39s")
+    Xi, Xv, Y = z["B/Xi"].tolist(), z["B/Xv"].tolist(), z["B/Y"].tolist()
+    res = []
+    for on_device, persistent in ((True, 1), (True, 0), (False, 1)):
+        prev = lib.fmx_set_option(b"online_persistent", persistent)
+        try:
+            m = build("NFMOnn", meta, 1, update_rule="ftrl", ftrl=dict(alpha=0.05, beta=1.0, l1=0.0, l2=0.0))
+            m.load_state_dict(sub(z, "B/sd0"))
+            m.device_online_loop = on_device
+            assert m._device_loop_ok() == on_device
+            t, acc, roc, cm = m.run_experiment(Xi, Xv, Y)
+            res.append((acc, roc, cm, sd_np(m)))
+        finally:
+            lib.fmx_set_option(b"online_persistent", prev)
+    assert res[0][:3] == res[1][:3] == res[2][:3]
+    for k in res[1][3]:
+        np.testing.assert_array_equal(res[0][3][k], res[1][3][k], err_msg=k)
+        assert_close(res[0][3][k], res[2][3][k], 1e-5, 1e-7, k)
