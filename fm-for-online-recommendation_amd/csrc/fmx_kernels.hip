@@ -2488,12 +2488,12 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
       g.M = H;
       g.N = in;
       g.K = B;
-      // as many splits of the batch as keep the grid within one workgroup per CU (139 KB of LDS each), at most B / 256
+      // as many splits of the batch as keep a layer's grid within two workgroups per CU (70 KB of LDS each), at most B / 256
       const int tiles = ((in + G_BN - 1) / G_BN) * ((H + G_BM - 1) / G_BM);
-      int n_split = 256 / tiles;
+      int n_split = 512 / tiles;
       if (n_split > w.n_split) n_split = w.n_split;
       if (n_split < 1) n_split = 1;
-      g.k_chunk = ((B + n_split - 1) / n_split + G_BK - 1) / G_BK * G_BK;
+      g.k_chunk = ((B + n_split - 1) / n_split + G_BK_WGRAD - 1) / G_BK_WGRAD * G_BK_WGRAD;
       n_split = (B + g.k_chunk - 1) / g.k_chunk;
       splits[l] = n_split;
       g.c_split_stride = (long long)H * w.ldp[l];
@@ -2537,11 +2537,12 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
     static bool raised = false;
     if (!raised) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)G_LDS_BYTES);
+                                (int)g_lds_bytes(G_BK_WGRAD));
       raised = true;
     }
     // grid x = the GEMM's column tiles + one slice for the bias columns (y there = blocks of 64 columns of dH_l)
-    hipLaunchKernelGGL(k_mlp_wgrad, dim3(wgx + 1, (H + G_BM - 1) / G_BM, wb.z_end[wb.n - 1]), dim3(256), G_LDS_BYTES, st, wb);
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3(wgx + 1, (H + G_BM - 1) / G_BM, wb.z_end[wb.n - 1]), dim3(256), g_lds_bytes(G_BK_WGRAD), st,
+                       wb);
   }
   MlpReduceArgs a;
   long long biggest = 0;
