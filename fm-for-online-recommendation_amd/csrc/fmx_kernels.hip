@@ -426,6 +426,7 @@ __device__ __forceinline__ void forward_sample(const FwdArgs &a, const int b, co
 
 template <int LPR, int LAYOUT, int NPASS>
 __global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
+  __builtin_amdgcn_s_setprio(3);  // ahead of the side-stream sort's waves at the CU's instruction arbiter
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= a.B) return;  // wave-uniform
   forward_sample<LPR, LAYOUT, NPASS>(a, b, threadIdx.x & 63);
@@ -600,6 +601,7 @@ template <> struct CoefA<false> {
 // groups.  At the tail of a run: the row update when the run began in this tile, a partial record otherwise.
 template <int LPR, int LAYOUT, int RULE, bool HAS_GBI, bool INL>
 __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
+  __builtin_amdgcn_s_setprio(3);  // ahead of the side-stream sort's waves at the CU's instruction arbiter
   constexpr int SLOTS = WAVE / LPR;  // lane groups
   constexpr int EPG = LPR;           // consecutive occurrences per group
   constexpr int REC = 2 * LPR * 4 + 4;
