@@ -314,8 +314,9 @@ def main():
 
         def run(n, first=0):
             # the index all-gather and the global sort of later steps run ahead on prefetch streams: two steps ahead when
-            # a step is one exact update, one step (= its sub-steps) ahead when the global batch is split
-            depth = 2 if dp._sub_steps(BATCH) == 1 else 1
+            # a step is one exact update over 16,384 samples (its sort takes longer than the step), else one step (= all
+            # its sub-steps when the global batch is split)
+            depth = 2 if (dp._sub_steps(BATCH) == 1 and BATCH * world >= 16384) else 1   # one 8,192-entry sort keeps up alone
             out = None
             for d in range(min(depth, n)):
                 dp.prefetch(idx_pool[(first + d) % N_POOL])
