@@ -1,0 +1,1 @@
+"""models: part of the drop-in mirror of the reference's import paths."""
