@@ -127,3 +127,64 @@ def test_prefetch_slots_and_sub_steps_equal_plain_steps(cap, depth):
     assert [float(l[0]) for l in losses] == ref_losses
     np.testing.assert_array_equal(t.rows.cpu().numpy(), t_ref.rows.cpu().numpy())
     np.testing.assert_array_equal(t.bias.cpu().numpy(), t_ref.bias.cpu().numpy())
+
+
+def _deep_run(rank, world):
+    """DeepFM steps through fmx.DeepFMTrainer (HIP tables, MFMA MLP section); returns (tables, MLP parameters)."""
+    import fmx
+    import torch.nn as nn
+    torch.manual_seed(3)
+    H, L = 64, 2
+    layers = [nn.Linear(K if j == 0 else H, H).cuda() for j in range(L)]
+    t = _table(fmx)
+    # the weights layout for the SGD rule
+    tw = fmx.FlatTable(SIZES, K, layout="weights")
+    first, second = t.export_reference()
+    tw.load_reference(first, second)
+    eng = fmx.FMEngine(tw, max_batch=B_LOCAL * 2)
+    tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=0.01), "sgd"), layers, K, tw.kp, mlp_lr=0.01)
+    assert tr.native
+    sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL) if world > 1 else slice(None)
+    for idx, y in _batches(2):
+        idx_d, _, y_d = eng.to_device(idx[sl], None, y[sl])
+        tr.step(idx_d, y_d)
+    torch.cuda.synchronize()
+    eng.check_error_flag()
+    return tw.rows.cpu().numpy(), tr.flat.cpu().numpy()
+
+
+def _deep_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "fm-for-online-recommendation_amd")]
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank,) + _deep_run(rank, world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_deepfm_two_ranks_equal_one_process():
+    """DeepFMTrainer over the HIP backend at world size 2 (shared GPU, gloo with host staging): gathered low-rank factors
+    + one all-reduce of the MLP gradients == the single-process step on the same global batches.  The all-reduce adds the
+    two half-batch gradient sums in a different order than one process adds the full batch: 1e-5 on values."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_deep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref_rows, ref_mlp = _deep_run(0, 1)
+    np.testing.assert_array_equal(res[0][1], res[1][1])           # replicas identical to each other
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    for _, rows, mlp in res:
+        np.testing.assert_allclose(rows, ref_rows, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(mlp, ref_mlp, rtol=1e-5, atol=1e-6)
