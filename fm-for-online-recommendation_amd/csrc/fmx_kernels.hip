@@ -461,27 +461,44 @@ struct UpdArgs {
 // tile meta states
 constexpr int LEAD_NONE = 0, LEAD_CLOSES = 1, LEAD_THROUGH = 2;
 
-// deterministic block reduction of src[0..n): every thread sums a strided set of 16-byte groups (all loads of a thread
-// are independent and issued together), then an LDS tree.  The order depends only on (n, blockDim).
+// deterministic block reduction of src[0..n): every thread sums a strided set of elements (16-byte groups when dense),
+// 16 independent loads in flight per round -- at B = 16,384 with 128 threads a 4-deep unroll left 32 dependent rounds of
+// HBM latency per sum and the one workgroup that owns the bias became the longest path of the launch -- then an LDS tree.
+// The order of the additions depends only on (n, ld == 1, blockDim).
 __device__ float block_sum(const float *src, int n, int ld, float *sm) {
+  constexpr int U = 16;
+  const int tid = threadIdx.x, nt = blockDim.x;
   float acc = 0.f;
   if (ld == 1) {
     const int n4 = n >> 2;
     const float4 *src4 = reinterpret_cast<const float4 *>(src);
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-      const float4 v = src4[i];
-      acc += (v.x + v.y) + (v.z + v.w);
+    for (int i0 = tid; i0 < n4; i0 += U * nt) {
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * nt;
+        v[u] = i < n4 ? src4[i] : float4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
     }
-    for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += src[i];
-  } else {  // strided sample records: same order of additions per thread as the dense form would give for n4 = 0
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += src[(size_t)i * ld];
+    for (int i = (n4 << 2) + tid; i < n; i += nt) acc += src[i];
+  } else {  // strided sample records
+    for (int i0 = tid; i0 < n; i0 += U * nt) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * nt;
+        v[u] = i < n ? src[(size_t)i * ld] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += v[u];
+    }
   }
-  sm[threadIdx.x] = acc;
+  sm[tid] = acc;
   __syncthreads();
-  for (int w = blockDim.x >> 1; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+  for (int w = nt >> 1; w > 0; w >>= 1) {
+    if (tid < w) sm[tid] += sm[tid + w];
     __syncthreads();
   }
   const float r = sm[0];

@@ -33,46 +33,59 @@ class HipBackend:
         self.e, self.hyper, self.rule, self.loss = engine, hyper, rule, loss
         self.max_global_batch = max_step_batch(max(engine.table.feature_sizes))
 
-    def forward(self, idx, y, inv_b):
+    def forward(self, idx, y, inv_b, stream=None):
         """-> records [B, kp + 4]: per sample (S[kp], dz, loss, pad) -- one buffer, so ONE all-gather carries everything
         the global update needs from this rank."""
         B = idx.shape[0]
         if getattr(self, "_rec", None) is None or self._rec.shape[0] < B:
             self._rec = torch.zeros((B, self.e.table.kp + 4), dtype=torch.float32, device=self.e.device)
-        rec = self._rec[:B]
-        self.e.forward(self.hyper, idx, None, y, loss=self.loss, inv_b=inv_b, want_first=False, want_bi=False, records=rec)
+            self._rec_views = {}
+        rec = self._rec_views.get(B)
+        if rec is None:
+            rec = self._rec_views[B] = self._rec[:B]
+        self.e.forward(self.hyper, idx, None, y, loss=self.loss, inv_b=inv_b, want_first=False, want_bi=False, records=self._rec,
+                       stream=stream)
         return rec
 
     N_SLOTS = 4   # batches that may be gathered + sorted ahead of their update, each with a workspace of its own
+    takes_stream = True   # forward / update accept the caller's stream (saves a current_stream() lookup per launch)
 
     def _slot_ws(self, slot, GB):
         if not hasattr(self, "_ws"):
-            self._ws = {}
+            self._ws, self._ws_need = {}, {}
+        need = self._ws_need.get(GB)
+        if need is None:
+            need = self._ws_need[GB] = int(self.e.lib.fmx_workspace_bytes(self.e.table.c_struct(), GB)) // 4
         ws = self._ws.get(slot)
-        need = int(self.e.lib.fmx_workspace_bytes(self.e.table.c_struct(), GB)) // 4
         if ws is None or ws.numel() < need:
             ws = self._ws[slot] = self.e.new_workspace(GB)
         return ws
 
-    def start_sort(self, idx_g, slot=0):
-        """The global occurrence sort only needs the gathered indices; it is launched on the CURRENT stream (the caller
-        runs it on a prefetch stream) into the slot's own workspace."""
+    def start_sort(self, idx_g, slot=0, stream=None):
+        """The global occurrence sort only needs the gathered indices; it is launched on `stream` (the caller's prefetch
+        stream; default: the current stream) into the slot's own workspace."""
         e = self.e
-        e._ensure(idx_g.shape[0])
-        e.sort(idx_g, workspace=self._slot_ws(slot, idx_g.shape[0]))
+        GB = idx_g.shape[0]
+        e._ensure(GB)
+        had = getattr(self, "_ws", {}).get(slot)
+        ws = self._slot_ws(slot, GB)
+        if ws is not had and stream is not None and not isinstance(stream, int):
+            # a workspace allocated just now was zero-filled on the CURRENT stream: the sort must not overtake the fill
+            stream.wait_stream(torch.cuda.current_stream(e.device))
+        e.sort(idx_g, workspace=ws, stream=stream)
 
-    def update(self, idx_g, rec_g, inv_b, slot=None):
+    def update(self, idx_g, rec_g, inv_b, slot=None, stream=None):
         """Row-reduced update over the global batch (sorted into `slot` by start_sort, or here); returns the mean-loss
         tensor [1]."""
         e = self.e
         GB = idx_g.shape[0]
         e._ensure(GB)
         if slot is None:                                      # nothing prepared: sort here, in the engine's own workspace
-            e.sort(idx_g)
+            e.sort(idx_g, stream=stream)
             ws = None
         else:
             ws = self._slot_ws(slot, GB)
-        e.update(self.hyper, self.rule, GB, None, None, inv_b=inv_b, with_loss=True, records=rec_g, workspace=ws)
+        e.update(self.hyper, self.rule, GB, None, None, inv_b=inv_b, with_loss=True, records=rec_g, workspace=ws, stream=stream)
         return e.loss_out
 
 
@@ -134,7 +147,7 @@ class DataParallelFM:
         if not (idx_next.is_cuda and hasattr(self.backend, "start_sort")):
             return
         if not hasattr(self, "_pref"):
-            self._pref, self._next_slot, self._slot_free, self._pf_streams = {}, 0, {}, {}
+            self._pref, self._next_slot, self._pf_streams = {}, 0, {}
         B = idx_next.shape[0]
         n_sub = self._sub_steps(B)
         Bs = B // n_sub
@@ -142,19 +155,27 @@ class DataParallelFM:
         if len(self._pref) + n_sub > n_slots:
             return                                            # no free slot: the step will gather and sort by itself
         dev = idx_next.device
+        cur = torch.cuda.current_stream(dev)
         for j in range(n_sub):
-            part = idx_next[j * Bs:(j + 1) * Bs]
+            part = idx_next[j * Bs:(j + 1) * Bs] if n_sub > 1 else idx_next
             slot = self._next_slot
             self._next_slot = (slot + 1) % n_slots
-            pf = self._pf_streams.get(slot)
-            if pf is None:
-                pf = self._pf_streams[slot] = torch.cuda.Stream(device=dev)
-            pf.wait_stream(torch.cuda.current_stream(dev)) if slot not in self._slot_free else pf.wait_event(self._slot_free[slot])
-            with torch.cuda.stream(pf):
-                idx_g = self._gathered(f"idx_slot{slot}", part)
-                self.backend.start_sort(idx_g, slot)
-                ready = torch.cuda.Event()
-                ready.record(pf)
+            st = self._pf_streams.get(slot)
+            if st is None:
+                # per slot: a prefetch stream, a "gathered + sorted" event and a "slot free again" event, all reused
+                st = self._pf_streams[slot] = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
+                st[0].wait_stream(cur)
+            else:
+                st[0].wait_event(st[2])                       # the update that last used this slot has run
+            pf, ready = st[0], st[1]
+            if self.world > 1:                                # the collective goes to whatever stream is current
+                with torch.cuda.stream(pf):
+                    idx_g = self._gathered(f"idx_slot{slot}", part)
+                    self.backend.start_sort(idx_g, slot, stream=pf)
+            else:
+                idx_g = part
+                self.backend.start_sort(idx_g, slot, stream=pf)
+            ready.record(pf)
             self._pref[part.data_ptr()] = (idx_g, slot, ready)
 
     def _step(self, idx_local, y_local):
@@ -163,16 +184,15 @@ class DataParallelFM:
         pref = getattr(self, "_pref", {}).pop(idx_local.data_ptr(), None) if idx_local.is_cuda else None
         if pref is not None and pref[0].shape[0] != B * self.world:
             pref = None
-        rec = self.backend.forward(idx_local, y_local, inv_b)
+        cur = torch.cuda.current_stream(idx_local.device) if idx_local.is_cuda else None   # looked up once per step
+        kw = {"stream": cur} if cur is not None and getattr(self.backend, "takes_stream", False) else {}
+        rec = self.backend.forward(idx_local, y_local, inv_b, **kw)
         rec_g = self._gathered("rec", rec)
         if pref is None:                                      # nothing prepared: gather and sort in line
             idx_g = self._gathered("idx", idx_local)
-            return self.backend.update(idx_g, rec_g, inv_b)
+            return self.backend.update(idx_g, rec_g, inv_b, **kw)
         idx_g, slot, ready = pref
-        cur = torch.cuda.current_stream(idx_local.device)
         cur.wait_event(ready)
-        out = self.backend.update(idx_g, rec_g, inv_b, slot)
-        free = torch.cuda.Event()
-        free.record(cur)
-        self._slot_free[slot] = free                          # the slot's buffers may be overwritten after this update
+        out = self.backend.update(idx_g, rec_g, inv_b, slot, **kw)
+        self._pf_streams[slot][2].record(cur)                 # the slot's buffers may be overwritten after this update
         return out

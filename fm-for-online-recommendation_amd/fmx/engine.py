@@ -75,8 +75,12 @@ class FMEngine:
         if B > self.max_batch:
             self._alloc(B)
 
-    def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+    def _stream(self, stream=None):
+        """The HIP stream handle a launch goes to: `stream` (an int handle or a torch stream) when the caller already has
+        it -- torch.cuda.current_stream() costs several microseconds per call -- else torch's current stream."""
+        if stream is None:
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return stream if isinstance(stream, int) else stream.cuda_stream
 
     def _fwd_out(self, want_first=True, want_bi=True):
         o = _lib.FwdOut()
@@ -95,20 +99,27 @@ class FMEngine:
         return idx_d, xv_d, y_d
 
     # ---- kernels ----
-    def forward(self, hyper, idx_d, xv_d=None, y_d=None, loss=None, inv_b=None, want_first=True, want_bi=True, records=None):
+    def forward(self, hyper, idx_d, xv_d=None, y_d=None, loss=None, inv_b=None, want_first=True, want_bi=True, records=None,
+                stream=None):
         """records: optional [B, ld] fp32 tensor (ld >= kp + 2, multiple of 4): S, dz and loss are written as fields of one
         per-sample record (S = rec[:kp], dz = rec[kp], loss = rec[kp + 1]) instead of the engine's dense buffers."""
         B = idx_d.shape[0]
         self._ensure(B)
-        out = self._fwd_out(want_first, want_bi)
+        key = (want_first, want_bi, None if records is None else (records.data_ptr(), records.shape[1]), self.S.data_ptr())
+        cached = getattr(self, "_fwd_cache", None)
+        if cached is None or cached[0] != key:     # the output struct only changes with the buffers it points at
+            out = self._fwd_out(want_first, want_bi)
+            if records is not None:
+                kp, ld = self.table.kp, records.shape[1]
+                assert ld >= kp + 2 and ld % 4 == 0 and records.is_contiguous()
+                base = records.data_ptr()
+                out.S, out.dz, out.loss, out.sample_ld = base, base + 4 * kp, base + 4 * (kp + 1), ld
+            self._fwd_cache = cached = (key, out)
         if records is not None:
-            kp, ld = self.table.kp, records.shape[1]
-            assert records.shape[0] >= B and ld >= kp + 2 and ld % 4 == 0 and records.is_contiguous()
-            base = records.data_ptr()
-            out.S, out.dz, out.loss, out.sample_ld = base, base + 4 * kp, base + 4 * (kp + 1), ld
+            assert records.shape[0] >= B
         inv_b = 1.0 / B if inv_b is None else inv_b
         _lib.check(self.lib.fmx_fm_forward(self.table.c_struct(), hyper.ref(), idx_d.data_ptr(), _ptr(xv_d), _ptr(y_d), B,
-                                           _lib.LOSSES[loss], inv_b, C.byref(out), self._stream()))
+                                           _lib.LOSSES[loss], inv_b, C.byref(cached[1]), self._stream(stream)))
         return B
 
     def new_workspace(self, B):
@@ -117,15 +128,15 @@ class FMEngine:
         nbytes = int(self.lib.fmx_workspace_bytes(self.table.c_struct(), B))
         return torch.zeros(nbytes // 4, dtype=torch.int32, device=self.device)
 
-    def sort(self, idx_d, workspace=None):
+    def sort(self, idx_d, workspace=None, stream=None):
         B = idx_d.shape[0]
         self._ensure(B)
         ws = self.workspace if workspace is None else workspace
         _lib.check(self.lib.fmx_sort_occurrences(self.table.c_struct(), idx_d.data_ptr(), B, ws.data_ptr(),
-                                                 self.error.data_ptr(), self._stream()))
+                                                 self.error.data_ptr(), self._stream(stream)))
 
     def update(self, hyper, rule, B, xv_d, dz_first, dz_bi=None, gbi=None, inv_b=None, with_loss=True, S=None, loss_b=None,
-               records=None, fm_term=True, workspace=None):
+               records=None, fm_term=True, workspace=None, stream=None):
         """Row-reduced backward + fused update for the batch whose occurrences self.sort() just listed.
         S / loss_b default to the buffers the last forward() filled (a data-parallel caller passes gathered ones, or
         `records` [B, ld] as written by forward(records=...): then dz_first = dz_bi = the records' dz field)."""
@@ -144,7 +155,7 @@ class FMEngine:
         _lib.check(self.lib.fmx_fm_update(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], ws.data_ptr(),
                                           _ptr(xv_d), S_p, dzf_p, dzb_p, _ptr(gbi), B, ld,
                                           loss_p if with_loss else None, inv_b,
-                                          self.loss_out.data_ptr() if with_loss else None, self._stream()))
+                                          self.loss_out.data_ptr() if with_loss else None, self._stream(stream)))
 
     def step(self, hyper, rule, loss, idx_d, xv_d, y_d, inv_b=None):
         """One pure-FM mini-batch step; the mean loss lands in self.loss_out[0] (no sync here)."""
