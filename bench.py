@@ -313,10 +313,10 @@ def main():
         dp = fmx.DataParallelFM(fmx.HipBackend(eng, hyper, RULE, "logits"))
 
         def run(n, first=0):
-            # the index all-gather and the global sort of later steps run ahead on prefetch streams: two steps ahead when
-            # a step is one exact update over 16,384 samples (its sort takes longer than the step), else one step (= all
-            # its sub-steps when the global batch is split)
-            depth = 2 if (dp._sub_steps(BATCH) == 1 and BATCH * world >= 16384) else 1   # one 8,192-entry sort keeps up alone
+            # the index all-gather and the global sort of later steps run ahead on two prefetch streams: two steps ahead when
+            # a step is one exact update (two global sorts in flight: one alone is as long as the step or longer), one
+            # step (= all its sub-steps) ahead when the global batch is split
+            depth = 2 if dp._sub_steps(BATCH) == 1 else 1
             out = None
             for d in range(min(depth, n)):
                 dp.prefetch(idx_pool[(first + d) % N_POOL])

@@ -162,8 +162,13 @@ class DataParallelFM:
             self._next_slot = (slot + 1) % n_slots
             st = self._pf_streams.get(slot)
             if st is None:
-                # per slot: a prefetch stream, a "gathered + sorted" event and a "slot free again" event, all reused
-                st = self._pf_streams[slot] = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
+                # per slot: a "gathered + sorted" event and a "slot free again" event, both reused; the slots share TWO
+                # prefetch streams (a process gets few hardware queues: with a stream per slot some prefetch stream ends up
+                # in the queue of the main stream and its sort waits behind the step it was meant to overlap)
+                shared = self._pf_streams.get(("stream", slot % 2))
+                if shared is None:
+                    shared = self._pf_streams[("stream", slot % 2)] = torch.cuda.Stream(device=dev)
+                st = self._pf_streams[slot] = (shared, torch.cuda.Event(), torch.cuda.Event())
                 st[0].wait_stream(cur)
             else:
                 st[0].wait_event(st[2])                       # the update that last used this slot has run
