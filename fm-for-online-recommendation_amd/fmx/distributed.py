@@ -95,18 +95,20 @@ class DataParallelFM:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._gloo = dist.is_initialized() and dist.get_backend(group) == "gloo"     # looked up once, not per collective
         self._bufs = {}
 
     def _gathered(self, name, local):
         """all_gather `local` ([B, ...] contiguous) into a rank-major [G*B, ...] buffer."""
         if self.world == 1:
             return local
-        shape = (self.world * local.shape[0],) + tuple(local.shape[1:])
-        key = (name, shape, local.dtype, local.device)
+        key = (name, local.shape[0])
         out = self._bufs.get(key)
-        if out is None:
+        if out is None or out.dtype != local.dtype or out.device != local.device or out.shape[1:] != local.shape[1:]:
+            shape = (self.world * local.shape[0],) + tuple(local.shape[1:])
             out = self._bufs[key] = torch.empty(shape, dtype=local.dtype, device=local.device)
-        if local.is_cuda and dist.get_backend(self.group) == "gloo":
+        shape = out.shape
+        if self._gloo and local.is_cuda:
             # rehearsal only (several ranks sharing one GPU, where RCCL cannot run): stage through the host
             host = torch.empty(shape, dtype=local.dtype)
             dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=self.group)
