@@ -236,3 +236,27 @@ def test_rrf_online_vs_reference(task, golden_dir, capsys):
     np.testing.assert_allclose(m.gamma.numpy(), z[f"{task}/RRF/gamma"], rtol=1e-8, atol=1e-11)
     with pytest.raises(NotImplementedError):
         RRF_Online(torch.DoubleTensor(z["cls/X"]), torch.DoubleTensor(z["cls/y"]), "cls", loss_type="x").online_learning()
+
+
+def test_exact_step_capacity_and_sub_steps():
+    """The largest batch one exact step can take (32-bit (index, sample) composites sorted inside one workgroup's LDS) and
+    how DataParallelFM splits a global batch that exceeds it."""
+    import fmx
+    from fmx.distributed import DataParallelFM, max_step_batch
+    assert max_step_batch(3) == 32768                       # LDS sort width
+    assert max_step_batch((1 << 17) - 1) == 32768           # 17 index bits + 15 sample bits, 0xFFFFFFFF stays free
+    assert max_step_batch(1 << 17) == 16384                 # index 2^17 - 1 with sample 2^15 - 1 would be 0xFFFFFFFF
+    assert max_step_batch((1 << 18) - 1) == 16384           # 18 index bits (the Criteo list's largest field)
+    assert max_step_batch(1 << 18) == 8192
+    assert max_step_batch((1 << 20) - 1) == 4096            # 20 index bits + 12 sample bits
+    assert max_step_batch(1 << 24) == 128
+
+    class Backend:
+        max_global_batch = 16384
+
+    dp = DataParallelFM(Backend())
+    assert dp.world == 1 and dp._sub_steps(4096) == 1 and dp._sub_steps(16384) == 1 and dp._sub_steps(32768) == 2
+    dp.world = 8
+    assert dp._sub_steps(4096) == 2 and dp._sub_steps(2048) == 1 and dp._sub_steps(16384) == 8
+    dp.world = 4
+    assert dp._sub_steps(4096) == 1
