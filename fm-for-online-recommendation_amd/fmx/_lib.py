@@ -20,6 +20,9 @@ EXPORTS = ["fmx_version", "fmx_last_error_string", "fmx_set_option", "fmx_sorted
            "fmx_sort_occurrences", "fmx_fm_update", "fmx_fm_step", "fmx_fm_stream", "fmx_stream_read"]
 
 
+I64_RETURNS = ("fmx_workspace_bytes", "fmx_mlp_section_workspace_bytes")   # byte counts: int64_t in include/fmx.h
+
+
 class FmxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libfmx error {code}: {msg}")
@@ -86,7 +89,7 @@ def load():
     lib.fmx_mlp_section.argtypes = [MP, i32, p, i32, p, p, i32, f32, p, p, p, p, i32, p, f32, p, p]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name == "fmx_workspace_bytes":
+        if name in I64_RETURNS:
             fn.restype = C.c_int64
         elif name != "fmx_last_error_string":
             fn.restype = C.c_int

@@ -164,13 +164,32 @@ class OnlineFMBase(nn.Module):
                 self.s.copy_(sd["s"].float().cpu())
                 self.alpha = sd["alpha"].float().clone().to(self.device)
 
+    # ---- the optimizer state of update_rule='ftrl' (an extension: the reference has no such rule).  state_dict() keeps
+    #      the reference's keys, i.e. the derived weights only; a resumed FTRL run also needs every coordinate's (z, n),
+    #      or all per-coordinate learning rates restart from n = 0 ----
+    def ftrl_state_dict(self):
+        """{'zV' [R,k], 'nV' [R,k], 'zw' [R], 'nw' [R], 'bias_zn' [2]} on the CPU (rows flat over the fields, as in the
+        table); None for the other rules."""
+        if self.update_rule != "ftrl":
+            return None
+        zV, nV, zw, nw = self._table.export_ftrl_state()
+        return {"zV": zV, "nV": nV, "zw": zw, "nw": nw, "bias_zn": self._table.bias.detach().cpu().clone()}
+
+    def load_ftrl_state_dict(self, st):
+        """Restore (z, n) bit for bit; V, w and the bias weight are re-derived from it exactly as an update does."""
+        if self.update_rule != "ftrl":
+            raise ValueError("load_ftrl_state_dict: this model does not use update_rule='ftrl'")
+        self._table.load_ftrl_state(st["zV"], st["nV"], st["zw"], st["nw"])
+        self._table.bias.copy_(torch.as_tensor(st["bias_zn"], dtype=torch.float32).to(self.device))
+
     # pickle support (reference main_experiment.py:160-162 pickles the whole model): tensors go through the CPU
     def __getstate__(self):
         return {"ctor": dict(feature_sizes=list(self.feature_sizes), embedding_size=self.embedding_size,
                              num_hidden_layers=self.num_hidden_layers,
                              neuron_per_hidden_layer=self.neuron_per_hidden_layer, batch_size=self.batch_size,
                              num_classes=self.num_classes, update_rule=self.update_rule, ftrl=dict(self._ftrl)),
-                "cls": self._name, "state_dict": {k: v.cpu() for k, v in self.state_dict().items()}}
+                "cls": self._name, "state_dict": {k: v.cpu() for k, v in self.state_dict().items()},
+                "ftrl_state": self.ftrl_state_dict()}
 
     def __setstate__(self, state):
         ctor = state["ctor"]
@@ -179,6 +198,8 @@ class OnlineFMBase(nn.Module):
                               neuron_per_hidden_layer=ctor["neuron_per_hidden_layer"], batch_size=ctor["batch_size"],
                               num_classes=ctor["num_classes"], update_rule=ctor["update_rule"], ftrl=ctor["ftrl"])
         self.load_state_dict(state["state_dict"])
+        if state.get("ftrl_state") is not None:       # after the weights: (z, n) is the state, V / w / bias follow from it
+            self.load_ftrl_state_dict(state["ftrl_state"])
 
     # ------------------------------------------------------------------------------------------------------
     # forward pieces (reference deepfm_adam.py:46-89)

@@ -67,3 +67,29 @@ def assert_state_close(sd_a, sd_b, sd_prev=None, rtol=1e-5, what="", sign_rule=N
             assert not (derr > dtol).any(), (f"{what}/{k} (delta): {int((derr > dtol).sum())}/{a.size} off; max abs err "
                                              f"{derr.max():.3e}, max |ref delta| {dscale:.3e}")
 
+
+
+def assert_within_f64(a, ref, floor, what, rtol=1e-5):
+    """|a - ref| <= 1e-5 |ref| + floor, element by element: north_star's tolerance against a float64 evaluation, with the
+    fp32 rounding floor of the quantity (oracle.fm_oracle.flat_fm_step_f64 derives it term by term) where the value is a
+    cancelled difference."""
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    assert a.shape == ref.shape, f"{what}: shape {a.shape} vs {ref.shape}"
+    err = np.abs(a - ref)
+    tol = rtol * np.abs(ref) + floor
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{a.size} beyond {rtol:g} rel + fp32 floor; worst err/tol "
+                           f"{float((err / np.maximum(tol, 1e-300)).max()):.2f}, max abs err {float(err.max()):.3e}")
+
+
+def assert_ftrl_step_within_f64(hip, ref, what=""):
+    """hip: the (z, n) state after the HIP step as dict(zV [R,k], nV, zw [R], nw, zb, nb); ref: flat_fm_step_f64's result
+    for the same step.  Touched rows within 1e-5 + floor of the float64 step, untouched rows bit-identical."""
+    u, new, fl = ref["urows"], ref["new"], ref["floor"]
+    for kk in ("zV", "nV", "zw", "nw"):
+        assert_within_f64(np.asarray(hip[kk])[u], new[kk][u], fl[kk], f"{what}{kk}")
+        mask = np.ones(len(new[kk]), dtype=bool)
+        mask[u] = False
+        np.testing.assert_array_equal(np.asarray(hip[kk])[mask], new[kk][mask].astype(np.float32), err_msg=f"{what}{kk} untouched rows")
+    assert_within_f64(hip["zb"], new["zb"], fl["zb"], f"{what}zb")
+    assert_within_f64(hip["nb"], new["nb"], fl["nb"], f"{what}nb")

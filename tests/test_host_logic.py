@@ -120,6 +120,19 @@ def test_library_exports_every_declared_symbol():
     assert (lib.fmx_sorted_bbits(1), lib.fmx_sorted_bbits(4096), lib.fmx_sorted_bbits(4097)) == (6, 12, 13)
 
 
+def test_byte_count_entry_points_return_int64():
+    """Both *_workspace_bytes functions are int64_t in include/fmx.h; a 32-bit restype truncates sizes beyond 2 GiB (the
+    MLP section's workspace at B = 32768, hidden = 2048, 8 layers is 6.4 GiB) and the caller would under-allocate."""
+    import ctypes as C
+    import fmx
+    lib = fmx._lib.load()
+    assert lib.fmx_workspace_bytes.restype is C.c_int64
+    assert lib.fmx_mlp_section_workspace_bytes.restype is C.c_int64
+    m = fmx._lib.Mlp(None, 8, 16, 2048, 0)
+    big = lib.fmx_mlp_section_workspace_bytes(C.byref(m), 32768)          # host arithmetic only: no GPU needed
+    assert big > (1 << 32), big
+
+
 def test_models_fail_loudly_without_a_gpu():
     import torch
     if torch.cuda.is_available():
