@@ -214,6 +214,27 @@ __device__ __forceinline__ void bitonic_local(uint32_t (&v)[E], int tid, int k, 
   }
 }
 
+// composites of samples i0 .. i0 + E - 1 of field f: every index load is issued before the first is used (a branch per
+// element -- range check, error flag -- made the compiler wait for each load in turn: E dependent HBM round trips)
+template <int E>
+__device__ __forceinline__ void load_composites(const SortArgs &a, int f, int i0, uint32_t vocab, uint32_t (&v)[E]) {
+  uint32_t li[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = i0 + r;
+    li[r] = (uint32_t)a.idx[(size_t)(i < a.B ? i : a.B - 1) * a.F + f];
+  }
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = i0 + r;
+    const bool in_range = li[r] < vocab;
+    v[r] = (i < a.B && in_range) ? ((li[r] << a.bbits) | (uint32_t)i) : SENT;
+    bad = bad || (i < a.B && !in_range);
+  }
+  if (bad && a.error) *a.error = 1;
+}
+
 // Device body of the occurrence sort of ONE field (the calling workgroup: nt threads, nt * E == Bp): the full bitonic
 // network, stages with partner distance < 64 E in registers / DPP, the cross-wave stages through LDS (Bp words); 78
 // dependent stages at Bp = 4096.  (Tried and removed: every wave sorting its 64 E composites in registers followed by
@@ -223,17 +244,7 @@ __device__ __forceinline__ void sort_field(const SortArgs &a, int f, uint32_t *s
   const int tid = threadIdx.x, nt = blockDim.x;
   const uint32_t vocab = (uint32_t)(a.foff[f + 1] - a.foff[f]);
   uint32_t v[E];
-#pragma unroll
-  for (int r = 0; r < E; ++r) {
-    const int i = tid * E + r;
-    uint32_t c = SENT;
-    if (i < a.B) {
-      const uint32_t li = (uint32_t)a.idx[(size_t)i * a.F + f];
-      if (li < vocab) c = (li << a.bbits) | (uint32_t)i;
-      else if (a.error) *a.error = 1;
-    }
-    v[r] = c;
-  }
+  load_composites<E>(a, f, tid * E, vocab, v);
   const int wave_span = 64 * E;  // elements held by one wave
   uint32_t *dst = a.sorted + (size_t)f * a.Bp;
   const int half = a.Bp >> 1;
@@ -273,6 +284,152 @@ __global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
     a.sorted += (size_t)j * a.sorted_stride;
   }
   sort_field<E>(a, blockIdx.x, sm);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_sort_chunk + k_sort_merge: the occurrence sort for Bp >= 2 * SORT_CHUNK, spread over the chip
+// ------------------------------------------------------------------------------------------------------------
+// One workgroup per field keeps a 4,096-composite sort on ONE CU: 78 dependent bitonic stages, VALU-issue bound there
+// (22 us per batch while 217 CUs idle).  Here a field's Bp composites are cut into chunks of SORT_CHUNK = 1,024:
+//   k_sort_chunk  workgroup (field, chunk, batch): 256 threads x 4 composites, the bitonic network on 1,024 (55 stages,
+//                 3 of them through LDS) -> `runs` [F, Bp], every chunk sorted;
+//   k_sort_merge  workgroup (field, chunk, batch): the field's C sorted chunks in LDS (Bp words, 16-byte loads); every
+//                 composite of chunk c finds its rank among the other chunks by binary search (stable: ties -- only the
+//                 0xFFFFFFFF padding ties -- count for earlier chunks, not for later ones) and is stored at
+//                 sorted[f][own index + sum of ranks].
+// The result is the same array the one-workgroup sort produces (composites are unique, so any correct sort gives the
+// same bits).  Block -> work mapping is XCD-aware (blocks b and b + 8 share an XCD and its L2): the F workgroups that
+// read one chunk's [1024, F] slab of idx (each 128-byte line of it holds 32 of a sample's 39 indices and is read by
+// the workgroups of 32 fields) sit on ONE XCD, so the slab is fetched from HBM once instead of once per XCD; likewise
+// the C merge workgroups of a field read the same Bp words.  Placement is for speed only.
+constexpr int SORT_CHUNK = 1024, SORT_CHUNK_E = 4, SORT_CHUNK_THREADS = SORT_CHUNK / SORT_CHUNK_E;
+// from this width on the chunked form is the faster one (MI355X, Criteo vocabulary, one batch per launch: 4,096: 15 vs 18.6 us
+// -- but 8 batches per launch 36 vs 31, the total VALU work being the same; 8,192: 20 vs 35; 16,384: 35 vs 74)
+constexpr int SORT_CHUNKED_MIN_WIDTH = 8192;
+
+struct ChunkArgs {
+  SortArgs s;          // s.sorted: the final lists; runs: the chunk-sorted intermediate, same shape
+  uint32_t *runs;
+  int64_t runs_stride; // elements between the batches of one launch
+  int32_t C;           // chunks per field = Bp / SORT_CHUNK
+};
+
+// (unit, inner) of this block: units are spread round-robin over the 8 XCDs, the `n_inner` blocks of a unit share one
+__device__ __forceinline__ bool xcd_unit(int n_units, int n_inner, int &unit, int &inner) {
+  const int b = blockIdx.x, x = b & 7, s = b >> 3;
+  inner = s % n_inner;
+  unit = (s / n_inner) * 8 + x;
+  return unit < n_units;
+}
+
+__global__ __launch_bounds__(SORT_CHUNK_THREADS) void k_sort_chunk(ChunkArgs a) {
+  constexpr int E = SORT_CHUNK_E;
+  __shared__ uint32_t sm[SORT_CHUNK];
+  int unit, f;
+  if (!xcd_unit(a.s.n_batches * a.C, a.s.F, unit, f)) return;
+  const int j = unit / a.C, c = unit - j * a.C;
+  const int32_t *idx = a.s.idx + (size_t)((a.s.pool_first + j) % a.s.n_pool) * a.s.pool_stride;
+  uint32_t *dst = a.runs + (size_t)j * a.runs_stride + (size_t)f * a.s.Bp + (size_t)c * SORT_CHUNK;
+  const int tid = threadIdx.x;
+  const uint32_t vocab = (uint32_t)(a.s.foff[f + 1] - a.s.foff[f]);
+  uint32_t v[E];
+  {
+    SortArgs sa = a.s;
+    sa.idx = idx;
+    load_composites<E>(sa, f, c * SORT_CHUNK + tid * E, vocab, v);
+  }
+  constexpr int wave_span = 64 * E;
+  for (int k = 2; k <= SORT_CHUNK; k <<= 1) {
+    int jj = k >> 1;
+    if (jj >= wave_span) {  // partner in another wave: through LDS
+#pragma unroll
+      for (int r = 0; r < E; ++r) sm[tid * E + r] = v[r];
+      __syncthreads();
+      for (; jj >= wave_span; jj >>= 1) {
+        for (int t = tid; t < SORT_CHUNK / 2; t += SORT_CHUNK_THREADS) {
+          const int i = 2 * t - (t & (jj - 1));
+          const int l = i + jj;
+          const uint32_t x = sm[i], y = sm[l];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { sm[i] = y; sm[l] = x; }
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int r = 0; r < E; ++r) v[r] = sm[tid * E + r];
+      __syncthreads();
+    }
+    bitonic_local<E>(v, tid, k, jj);
+  }
+  *reinterpret_cast<uint4 *>(dst + tid * E) = uint4{v[0], v[1], v[2], v[3]};
+}
+
+__global__ __launch_bounds__(SORT_CHUNK_THREADS) void k_sort_merge(ChunkArgs a) {
+  constexpr int E = SORT_CHUNK_E;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // the field's C sorted chunks: Bp words
+  int unit, c;
+  if (!xcd_unit(a.s.n_batches * a.s.F, a.C, unit, c)) return;
+  const int j = unit / a.s.F, f = unit - j * a.s.F;
+  const uint32_t *src = a.runs + (size_t)j * a.runs_stride + (size_t)f * a.s.Bp;
+  uint32_t *dst = a.s.sorted + (size_t)j * a.s.sorted_stride + (size_t)f * a.s.Bp;
+  const int tid = threadIdx.x;
+  // LDS image: element i of the field at word i + (i >> 5).  A binary search reads the odd multiples of 1024 / 2^d at
+  // depth d; unpadded, all of them fall into one or two of the 32 banks (up to 32-way conflicts, 8x the time over the 11
+  // steps: 13 us per launch); one pad word per 32 spreads every depth over the banks (at most 2-way).
+  auto at = [](int i) { return i + (i >> 5); };
+  {
+    uint4 t[8];  // up to Bp = 8 * 1024: every global load in flight before the first LDS store
+    const int n_it = a.s.Bp / (SORT_CHUNK_THREADS * 4);
+    for (int it0 = 0; it0 < n_it; it0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (it0 + u < n_it) t[u] = *reinterpret_cast<const uint4 *>(src + (it0 + u) * SORT_CHUNK_THREADS * 4 + tid * 4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (it0 + u < n_it) {
+          const int i = (it0 + u) * SORT_CHUNK_THREADS * 4 + tid * 4;  // i .. i + 3 share i >> 5
+          uint32_t *d4 = smem + at(i);
+          d4[0] = t[u].x; d4[1] = t[u].y; d4[2] = t[u].z; d4[3] = t[u].w;
+        }
+    }
+  }
+  __syncthreads();
+  uint32_t v[E];
+  int pos[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    v[r] = smem[at(c * SORT_CHUNK + tid * E + r)];
+    pos[r] = tid * E + r;
+  }
+  for (int o = 0; o < a.C; ++o) {
+    if (o == c) continue;  // workgroup-uniform
+    const uint32_t *run = smem + at(o * SORT_CHUNK);  // SORT_CHUNK is a multiple of 32: run[at(m)] is element m of the run
+    const bool before = o < c;  // ties: an equal composite of an earlier chunk goes first (stable)
+    // number of the run's composites that go before v[r] (ties: an equal composite of an EARLIER chunk goes first; only
+    // the 0xFFFFFFFF padding ties): fixed-step binary searches without branches -- a short-circuit in the comparison
+    // compiled to a branch and a wait per LDS read, 132 dependent reads per thread -- the E searches of a thread
+    // interleaved, so each step has E reads in flight
+    int cnt[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) cnt[r] = 0;
+#pragma unroll
+    for (int step = SORT_CHUNK / 2; step >= 1; step >>= 1) {
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const uint32_t m = run[at(cnt[r] + step - 1)];
+        const int goes_before = (int)(m < v[r]) | ((int)before & (int)(m == v[r]));
+        cnt[r] += goes_before ? step : 0;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < E; ++r) {  // cnt <= SORT_CHUNK - 1 here: one more comparison for the last element
+      const uint32_t m = run[at(cnt[r])];
+      cnt[r] += (int)(m < v[r]) | ((int)before & (int)(m == v[r]));
+      pos[r] += cnt[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r) dst[pos[r]] = v[r];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1533,6 +1690,9 @@ struct Tune {
                          // launch (k_fm_fixup) instead of the in-launch hand-off; both give identical bits
   int online_persistent = 1;  // FMX_ONLINE_PERSISTENT=0 / fmx_set_option("online_persistent", 0): fmx_online_run_mlp as per-sample launches
   int sort_ahead = 8;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..8)
+  int sort_chunked = 1;  // FMX_SORT_CHUNKED / fmx_set_option("sort_chunked", v): 0: one workgroup per field (k_sort_occ) at
+                         // every width; 1: k_sort_chunk + k_sort_merge from 8,192 composites per field on; 2: from 2,048 on.
+                         // Identical lists either way
 };
 Tune &tune() {
   static Tune t = [] {
@@ -1543,6 +1703,7 @@ Tune &tune() {
     if (const char *e = getenv("FMX_SORT_AHEAD")) x.sort_ahead = atoi(e);
     if (const char *e = getenv("FMX_ONLINE_PERSISTENT")) x.online_persistent = atoi(e);
     if (const char *e = getenv("FMX_INLINE_FIXUP")) x.inline_fixup = atoi(e);
+    if (const char *e = getenv("FMX_SORT_CHUNKED")) x.sort_chunked = atoi(e);
     auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
     if (!ok(x.wpb_fwd)) x.wpb_fwd = 2;
     if (!ok(x.wpb_upd)) x.wpb_upd = 2;
@@ -1558,6 +1719,7 @@ constexpr int SORT_AHEAD_MAX = 8;  // batches sorted per side-stream launch in f
 struct Workspace {
   uint32_t *sorted;       // buffer 0 of a ring of 2 * SORT_AHEAD_MAX buffers, `sorted_stride` elements apart
   size_t sorted_stride;
+  uint32_t *runs;         // SORT_AHEAD_MAX buffers of the same shape: the chunk-sorted intermediate of k_sort_chunk / k_sort_merge
   int32_t *meta;
   int32_t *counter;  // step counter of fmx_fm_stream (one int32 in its own 256-byte slot)
   float *parts;
@@ -1572,13 +1734,15 @@ Workspace carve(const fmx_table_t *t, int B, void *base) {
   const size_t F = (size_t)t->n_fields, Bp = (size_t)fmx_sorted_width(B), tiles = Bp >> 6;
   const size_t rec = 2 * (size_t)t->kp + 4;
   const size_t o_sorted1 = align_up(F * Bp * 4, 256);
-  const size_t o_meta = 2 * SORT_AHEAD_MAX * o_sorted1;
+  const size_t o_runs = 2 * SORT_AHEAD_MAX * o_sorted1;
+  const size_t o_meta = o_runs + (Bp >= 2 * SORT_CHUNK ? SORT_AHEAD_MAX * o_sorted1 : 0);
   const size_t o_counter = o_meta + align_up(F * tiles * 2 * 4, 256);
   const size_t o_parts = o_counter + 256;
   Workspace w;
   char *p = static_cast<char *>(base);
   w.sorted = reinterpret_cast<uint32_t *>(p);
   w.sorted_stride = o_sorted1 / 4;
+  w.runs = reinterpret_cast<uint32_t *>(p + o_runs);
   w.meta = reinterpret_cast<int32_t *>(p + o_meta);
   w.counter = reinterpret_cast<int32_t *>(p + o_counter);
   w.parts = reinterpret_cast<float *>(p + o_parts);
@@ -1723,8 +1887,23 @@ struct SortBatch {  // several batches of a pool in one launch
   int64_t pool_stride = 0, sorted_stride = 0;
 };
 
-int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t *sorted, int32_t *error, hipStream_t st,
-              const SortBatch *mb = nullptr) {
+int prepare_merge(int Bp) {
+  if ((size_t)(Bp + Bp / 32) * 4 <= 64 * 1024) return FMX_OK;
+  static std::mutex mu;
+  static bool raised = false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_merge), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (MAX_SORT_WIDTH + MAX_SORT_WIDTH / 32) * 4);
+    if (e != hipSuccess) return fail(FMX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    raised = true;
+  }
+  return FMX_OK;
+}
+
+// `runs`: the workspace's chunk-sort intermediate (Workspace::runs; used when Bp >= 2 * SORT_CHUNK)
+int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t *sorted, uint32_t *runs, int32_t *error,
+              hipStream_t st, const SortBatch *mb = nullptr) {
   SortArgs a;
   a.n_pool = mb ? mb->n_pool : 1;
   a.pool_first = mb ? mb->first : 0;
@@ -1739,6 +1918,20 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
   a.F = table->n_fields;
   a.Bp = fmx_sorted_width(B);
   a.bbits = fmx_sorted_bbits(B);
+  if (a.Bp >= (tune().sort_chunked > 1 ? 2 * SORT_CHUNK : SORT_CHUNKED_MIN_WIDTH) && tune().sort_chunked && runs) {
+    // chunk sort + rank merge, spread over the chip (k_sort_chunk / k_sort_merge)
+    if (int rc = prepare_merge(a.Bp)) return rc;
+    ChunkArgs c;
+    c.s = a;
+    c.runs = runs;
+    c.runs_stride = (int64_t)align_up((size_t)a.F * a.Bp * 4, 256) / 4;
+    c.C = a.Bp / SORT_CHUNK;
+    const int units1 = a.n_batches * c.C, grid1 = 8 * a.F * ((units1 + 7) / 8);
+    hipLaunchKernelGGL(k_sort_chunk, dim3(grid1), dim3(SORT_CHUNK_THREADS), 0, st, c);
+    const int units2 = a.n_batches * a.F, grid2 = 8 * c.C * ((units2 + 7) / 8);
+    hipLaunchKernelGGL(k_sort_merge, dim3(grid2), dim3(SORT_CHUNK_THREADS), (uint32_t)((a.Bp + a.Bp / 32) * sizeof(uint32_t)), st, c);
+    return check_launch("k_sort_chunk / k_sort_merge");
+  }
   if (int rc = prepare_sort(B)) return rc;
   // E elements per thread, Bp / E threads (a multiple of 64, at most 1024)
   int E = a.Bp <= 64 ? 1 : a.Bp <= 128 ? 2 : a.Bp <= 4096 ? 4 : a.Bp <= 8192 ? 8 : a.Bp <= 16384 ? 16 : 32;
@@ -1931,6 +2124,7 @@ int fmx_set_option(const char *name, int value) {
   if (!strcmp(name, "inline_fixup")) slot = &t.inline_fixup;
   else if (!strcmp(name, "sort_ahead")) slot = &t.sort_ahead;
   else if (!strcmp(name, "online_persistent")) slot = &t.online_persistent;
+  else if (!strcmp(name, "sort_chunked")) slot = &t.sort_chunked;
   else return fail(FMX_ERR_ARG, "fmx_set_option: unknown option '%s'", name);
   const int old = *slot;
   *slot = value;
@@ -1970,7 +2164,8 @@ int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B
   if (!idx || !workspace) return fail(FMX_ERR_ARG, "fmx_sort_occurrences: null argument");
   if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
   if (int rc = check_sort_geometry(table, B)) return rc;
-  return sort_impl(table, idx, B, carve(table, B, workspace).sorted, error, static_cast<hipStream_t>(stream));
+  const Workspace w = carve(table, B, workspace);
+  return sort_impl(table, idx, B, w.sorted, w.runs, error, static_cast<hipStream_t>(stream));
 }
 
 int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, void *workspace, const float *xv,
@@ -2002,12 +2197,12 @@ int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
   if (sd) {  // sort beside the forward pass: fork -> {side: sort} || {main: forward} -> join -> update
     (void)hipEventRecord(sd->fork, st);
     (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
-    if (int rc = sort_impl(table, idx, B, w.sorted, fwd->error, sd->stream)) return rc;
+    if (int rc = sort_impl(table, idx, B, w.sorted, w.runs, fwd->error, sd->stream)) return rc;
     (void)hipEventRecord(sd->sorted[0], sd->stream);
     if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
     (void)hipStreamWaitEvent(st, sd->sorted[0], 0);
   } else {
-    if (int rc = sort_impl(table, idx, B, w.sorted, fwd->error, st)) return rc;
+    if (int rc = sort_impl(table, idx, B, w.sorted, w.runs, fwd->error, st)) return rc;
     if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
   }
   return update_impl(table, hyper, rule, w, w.sorted, xv, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b, loss_out, st,
@@ -2057,7 +2252,7 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
       mb.n_batches = n;
       mb.pool_stride = (int64_t)B * (int64_t)F;
       mb.sorted_stride = (int64_t)w.sorted_stride;
-      return sort_impl(table, idx_pool, B, w.sorted + (size_t)(g & 1) * ahead * w.sorted_stride, fwd->error, where, &mb);
+      return sort_impl(table, idx_pool, B, w.sorted + (size_t)(g & 1) * ahead * w.sorted_stride, w.runs, fwd->error, where, &mb);
     };
     const int n_groups = (n_steps + ahead - 1) / ahead;
     if (sd && n_groups > 0) {
@@ -2126,7 +2321,7 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
       mb.n_batches = n;
       mb.pool_stride = (int64_t)B * (int64_t)F;
       mb.sorted_stride = (int64_t)w.sorted_stride;
-      rc = sort_impl(table, idx_pool, B, w.sorted, fwd->error, st, &mb);
+      rc = sort_impl(table, idx_pool, B, w.sorted, w.runs, fwd->error, st, &mb);
     }
     (void)hipEventRecord(e[1], st);
     for (int r = 0; r < n && rc == FMX_OK; ++r) {
@@ -2336,7 +2531,7 @@ int fmx_online_run_mlp(const fmx_table_t *table, const fmx_hyper_t *hyper, int32
     }
     if (int rc = mlp_launch(mlp, a, 1, table->kp, stream, "fmx_online_run_mlp")) return rc;
     if (hedge) continue;  // Hedge trains the hidden layers and alpha only (reference deepfm_onn.py:109-154)
-    if (int rc = sort_impl(table, idx_i, 1, w.sorted, fwd->error, st)) return rc;
+    if (int rc = sort_impl(table, idx_i, 1, w.sorted, w.runs, fwd->error, st)) return rc;
     if (int rc = update_impl(table, hyper, rule, w, w.sorted, xv_i, fwd->S, dz, fm_term ? dz : nullptr, gbi, 1, nullptr, 1.0f, nullptr,
                              st, nullptr, 0, fwd->error))
       return rc;

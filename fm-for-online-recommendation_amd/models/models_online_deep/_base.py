@@ -168,12 +168,15 @@ class OnlineFMBase(nn.Module):
     #      the reference's keys, i.e. the derived weights only; a resumed FTRL run also needs every coordinate's (z, n),
     #      or all per-coordinate learning rates restart from n = 0 ----
     def ftrl_state_dict(self):
-        """{'zV' [R,k], 'nV' [R,k], 'zw' [R], 'nw' [R], 'bias_zn' [2]} on the CPU (rows flat over the fields, as in the
-        table); None for the other rules."""
+        """{'zV' [R,k], 'nV' [R,k], 'zw' [R], 'nw' [R], 'bias_zn' [2], 'V_cached' [R,k], 'w_cached' [R]} on the CPU (rows flat
+        over the fields, as in the table); None for the other rules."""
         if self.update_rule != "ftrl":
             return None
         zV, nV, zw, nw = self._table.export_ftrl_state()
-        return {"zV": zV, "nV": nV, "zw": zw, "nw": nw, "bias_zn": self._table.bias.detach().cpu().clone()}
+        # V_cached / w_cached: the derived weights exactly as the last update stored them (the kernels derive them with
+        # 1-ulp v_rcp_f32 / v_sqrt_f32; re-deriving them on the host would differ in the last bit and the resumed run with it)
+        return {"zV": zV, "nV": nV, "zw": zw, "nw": nw, "bias_zn": self._table.bias.detach().cpu().clone(),
+                "V_cached": self._table.V.detach().cpu().clone(), "w_cached": self._table.w.detach().cpu().clone()}
 
     def load_ftrl_state_dict(self, st):
         """Restore (z, n) bit for bit; V, w and the bias weight are re-derived from it exactly as an update does."""
@@ -181,6 +184,9 @@ class OnlineFMBase(nn.Module):
             raise ValueError("load_ftrl_state_dict: this model does not use update_rule='ftrl'")
         self._table.load_ftrl_state(st["zV"], st["nV"], st["zw"], st["nw"])
         self._table.bias.copy_(torch.as_tensor(st["bias_zn"], dtype=torch.float32).to(self.device))
+        if st.get("V_cached") is not None:
+            self._table.V.copy_(torch.as_tensor(st["V_cached"], dtype=torch.float32).to(self.device))
+            self._table.w.copy_(torch.as_tensor(st["w_cached"], dtype=torch.float32).to(self.device))
 
     # pickle support (reference main_experiment.py:160-162 pickles the whole model): tensors go through the CPU
     def __getstate__(self):

@@ -77,7 +77,7 @@ def close(a, b, rtol, floor, what):
 # ---------------------------------------------------------------------------------------------------------
 # sort
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B", [1, 5, 64, 100, 1000, 4096])
+@pytest.mark.parametrize("B", [1, 5, 64, 100, 1000, 1025, 2048, 3000, 4096, 5000, 16384, 20000, 32768])
 def test_sort_bit_exact(fmx, B):
     pr = make_problem(MIXED_SIZES, 4, B, seed=B)
     t = weights_table(fmx, MIXED_SIZES, 4, pr)
@@ -94,6 +94,36 @@ def test_sort_bit_exact(fmx, B):
         want[:B] = np.sort(comp)
         np.testing.assert_array_equal(got[f], want)
     assert int(eng.error.item()) == 0
+
+
+def test_chunked_sort_equals_one_workgroup_sort(fmx):
+    """Wide sorts are k_sort_chunk + k_sort_merge (1,024-composite chunks spread over the chip, stable rank merge): by
+    default from 8,192 composites per field on, with fmx_set_option("sort_chunked", 2) from 2,048 on; 0 keeps one workgroup
+    per field at every width.  Same lists, bit for bit, including the 0xFFFFFFFF padding and an out-of-range index (which
+    becomes padding and raises the flag)."""
+    lib = fmx._lib.load()
+    for B in (2048, 4000, 4096, 9000):
+        pr = make_problem(MIXED_SIZES, 4, B, seed=B + 1, zipf=(B == 4000))
+        idx = pr["idx"].copy()
+        if B == 9000:
+            idx[17, 2] = MIXED_SIZES[2] + 5
+        t = weights_table(fmx, MIXED_SIZES, 4, pr)
+        eng = fmx.FMEngine(t, max_batch=B)
+        idx_d, _, _ = eng.to_device(idx)
+        got = []
+        for chunked in (2, 0):
+            old = lib.fmx_set_option(b"sort_chunked", chunked)
+            try:
+                eng.sorted.fill_(7)
+                eng.sort(idx_d)
+                torch.cuda.synchronize()
+                got.append(eng.sorted.cpu().numpy().view(np.uint32).copy())
+                assert int(eng.error.item()) == (1 if B == 9000 else 0)
+                eng.error.zero_()
+            finally:
+                lib.fmx_set_option(b"sort_chunked", old)
+        np.testing.assert_array_equal(got[0], got[1])
+        assert (np.diff(got[0].astype(np.int64), axis=1) >= 0).all()
 
 
 def test_out_of_range_index_is_flagged(fmx):
