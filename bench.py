@@ -156,9 +156,10 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
         loss = ll
         dist.destroy_process_group()
     if rank != 0:
-        return
+        return None
     mlp_params = sum(p.numel() for layer in layers for p in layer.parameters())
-    print(json.dumps({
+    flops = 6 * BATCH * (K_EMB * hidden + (n_layers - 1) * hidden * hidden)       # fwd + dgrad + wgrad of the three GEMMs
+    return ({
         "metric": "samples/sec online-DeepFM (Criteo-39-field, k=16, 3x256 relu MLP) SGD", "value": steps * BATCH * world / dt,
         "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -169,7 +170,10 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
                    "global_batch": BATCH * world,
                    "parallelism": "1 GPU" if world == 1 else f"dp{world}: all-gather of (idx, S, dz, dL/dbi) + one all-reduce "
                                                              "of the MLP gradients (exact)"},
-        "final_loss": float(loss)}))
+        "mlp_section": {"flop_per_step": flops, "note": "3 x (forward + dgrad + wgrad) fp32-MFMA GEMMs; TFLOP/s over the WHOLE step "
+                        "(tables included) is a lower bound of the section's rate", "TFLOPs_whole_step": flops / (dt / steps) / 1e12,
+                        "frac_of_fp32_mfma_peak_whole_step": flops / (dt / steps) / 1e12 / 157.3},
+        "final_loss": float(loss)})
 
 
 PUBLISHED_ONLINE = {"FMAdam": 39.1, "NFMAdam": 35.9, "NFMOnn": 27.9, "DeepFMAdam": 27.4, "DeepFMOnn": 18.4}
@@ -211,6 +215,27 @@ def bench_online(args, torch):
         "all_classes": rates, "vs_baseline_all": {k: rates[k] / PUBLISHED_ONLINE[k] for k in rates}}))
 
 
+def stream_read_probe(fmx, torch, dev):
+    """HBM-read ceiling on this GPU, same run: 16-byte loads over a 4 GiB buffer (fmx_stream_read), 5 timed passes."""
+    probe = torch.empty(1 << 30, dtype=torch.float32, device=dev)      # 4 GiB
+    probe.normal_()
+    sink = torch.zeros(1, device=dev)
+    lib = fmx._lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        fmx._lib.check(lib.fmx_stream_read(probe.data_ptr(), probe.numel() * 4, sink.data_ptr(), st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        fmx._lib.check(lib.fmx_stream_read(probe.data_ptr(), probe.numel() * 4, sink.data_ptr(), st))
+    e1.record()
+    torch.cuda.synchronize()
+    gbps = 5 * probe.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del probe
+    torch.cuda.empty_cache()
+    return gbps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +243,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05) indices instead of uniform (secondary workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary.deepfm block (BASELINE configs[3])")
     ap.add_argument("--loop-only", action="store_true", help="only the timed online loop (no measuring pass, no spread pass): "
                                                              "what tools/profile_round.sh traces for the in-loop kernel durations")
     ap.add_argument("--row-stride", type=int, default=0)
@@ -256,7 +282,10 @@ def main():
     if args.workload == "online":
         return bench_online(args, torch)
     if args.workload == "deepfm":
-        return bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal)
+        out = bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal)
+        if out is not None:
+            print(json.dumps(out))
+        return
     RULE = args.rule
     table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="ftrl" if RULE == "ftrl" else "weights", device=dev,
                           row_stride=args.row_stride if args.row_stride else None, ftrl=HYPER)
@@ -281,6 +310,10 @@ def main():
             torch.cuda.synchronize()
 
     kernel_ms = None
+    short_run = None
+    stream_gbps = None
+    if os.environ.get("FMX_BENCH_PROBE_FIRST", "0") == "1" and rank == 0:
+        stream_gbps = stream_read_probe(fmx, torch, dev)
     if world == 1:
         # ---- one GPU: the online loop of fmx_fm_stream over the resident pool.  Warm-up, then EXACTLY K timed steps ----
         eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.warmup, loss_buf)
@@ -292,6 +325,17 @@ def main():
         eng.check_error_flag()
         losses = loss_buf[:args.steps].cpu().numpy()
         assert np.isfinite(losses).all(), "non-finite loss in the timed region"
+        # what a 20-step call costs (the driver's round-end run is --steps 20 --warmup 5: pipeline start included)
+        if args.steps != 20 and not args.loop_only:
+            ts = []
+            for _ in range(5):
+                barrier()
+                tc = time.perf_counter()
+                eng.stream(hyper, RULE, "logits", idx_pool, y_pool, 20, loss_buf)
+                barrier()
+                ts.append(time.perf_counter() - tc)
+            short_run = {"steps_per_call": 20, "calls": 5, "median_ms_per_step": float(np.median(ts)) / 20 * 1e3,
+                         "median_samples_per_s": 20 * BATCH / float(np.median(ts))}
         # spread of the step time: 20 separately timed chunks of 100 steps (each chunk pays one pipeline start)
         chunk_us = []
         for _ in range(20 if args.steps >= 200 and not args.loop_only else 0):
@@ -349,33 +393,24 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    parallelism = f"dp{world}: replicated table, all-gather of (idx, S, dlogit), identical update on every replica (exact)"
 
-    # ---- HBM-read ceiling on this GPU, same run ----
-    probe = torch.empty(1 << 30, dtype=torch.float32, device=dev)      # 4 GiB
-    probe.normal_()
-    sink = torch.zeros(1, device=dev)
-    lib = fmx._lib.load()
-    st = torch.cuda.current_stream().cuda_stream
-    for _ in range(2):
-        fmx._lib.check(lib.fmx_stream_read(probe.data_ptr(), probe.numel() * 4, sink.data_ptr(), st))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        fmx._lib.check(lib.fmx_stream_read(probe.data_ptr(), probe.numel() * 4, sink.data_ptr(), st))
-    e1.record()
-    torch.cuda.synchronize()
-    stream_gbps = 5 * probe.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del probe
+    if stream_gbps is None:
+        stream_gbps = stream_read_probe(fmx, torch, dev)
 
     samples = args.steps * BATCH * world
     value = samples / dt
-    traffic = None
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_fm_update_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("k_fm_update_hbm_bytes_per_launch")
+            traffic_src = ("REPLAYED, not measured in this run: profiles/traffic_latest.json (" + str(tj.get("source", "rocprofv3 --pmc "
+                           "FETCH_SIZE / WRITE_SIZE passes of an earlier profiling run of this command")) + ")")
         except Exception:
             traffic = None
+    step_gbps = value / world * BYTES_STEP_FTRL / 1e9
     out = {
         "metric": "samples/sec online-FM (Criteo-39-field, k=16) FTRL-proximal",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -386,36 +421,52 @@ def main():
                                "labels Bernoulli(0.3)); BASELINE.json configs[1]+[2]",
                    "global_batch": BATCH * world, "row_stride_bytes": table.row_stride * 4, "rule": RULE,
                    "hyper": HYPER, "pool_batches": N_POOL,
-                   "parallelism": "1 GPU" if world == 1 else f"dp{world}: replicated table, all-gather of (idx, S, dlogit), "
-                                                             "identical update on every replica (exact)"},
-        "step_algorithmic": {"bytes_per_sample": BYTES_STEP_FTRL, "GBps": value / world * BYTES_STEP_FTRL / 1e9,
-                             "frac_of_peak": value / world * BYTES_STEP_FTRL / 1e9 / HBM_PEAK_GBPS,
-                             "frac_of_measured_stream_read": value / world * BYTES_STEP_FTRL / 1e9 / stream_gbps},
+                   "parallelism": "1 GPU" if world == 1 else parallelism},
         "measured_stream_read_GBps": stream_gbps,
         "final_loss": float(losses[-1]),
     }
+    # ---- roofline: the WHOLE STEP (samples/s x 10,772 algorithmic bytes per sample), timed in the
+    #      loop above; per-kernel figures beside it ----
+    roof = {"bound": "hbm", "scope": "whole step = sort + forward + update of one batch, as timed in `value`",
+            "achieved": step_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": step_gbps / HBM_PEAK_GBPS,
+            "frac_of_measured_stream_read": step_gbps / stream_gbps, "algorithmic_bytes_per_sample": BYTES_STEP_FTRL,
+            "algorithmic_bytes_per_step": BYTES_STEP_FTRL * BATCH,
+            "traffic": traffic, "traffic_scope": "k_fm_update, HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
+            "traffic_source": traffic_src}
     if kernel_ms is not None:
         sort_ms, fwd_ms, upd_ms, pair_ms = [v / n_meas for v in kernel_ms]
         if chunk_us:
             out["step_us_over_100_step_chunks"] = {q: float(np.percentile(chunk_us, p)) for q, p in (("p10", 10), ("p50", 50), ("p90", 90))}
         ach = BYTES_K_UPDATE * BATCH / (upd_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_fm_update", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                           "algorithmic_bytes_per_launch": BYTES_K_UPDATE * BATCH, "avg_launch_ms": upd_ms,
-                           "measured": "HIP events on the launch stream around groups of 8 back-to-back k_fm_update launches, "
-                                       "each on a different batch (empty event pair subtracted), in a measuring pass over "
-                                       "the same pool; profiles/ holds the rocprofv3 --kernel-trace --stats summary of the "
-                                       "same command"}
-        out["kernels_ms_per_launch"] = {"k_sort_occ": sort_ms, "k_fm_forward": fwd_ms, "k_fm_update": upd_ms,
-                                        "empty_event_pair": pair_ms}
-    else:
-        out["roofline"] = {"bound": "hbm", "kernel": "k_fm_update", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": None, "traffic": traffic, "measured": "per-kernel events are taken at N=1 only"}
+        ach_f = BYTES_K_FORWARD * BATCH / (fwd_ms * 1e-3) / 1e9
+        roof["kernels"] = {
+            "how": "HIP events on the launch stream around groups of 8 back-to-back launches of one kernel, each on a different "
+                   "batch (empty event pair subtracted), in a measuring pass over the same pool AFTER the timed loop: back-to-back "
+                   "launch durations, shorter than the same kernels inside the loop (dependent-launch gaps, the side-stream sort)",
+            "k_fm_update": {"achieved": ach, "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": BYTES_K_UPDATE * BATCH,
+                            "avg_launch_ms": upd_ms},
+            "k_fm_forward": {"achieved": ach_f, "frac": ach_f / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": BYTES_K_FORWARD * BATCH,
+                             "avg_launch_ms": fwd_ms},
+            "k_sort_occ": {"avg_launch_ms": sort_ms, "batches_per_launch": 8, "stream": "side stream, beside the steps"},
+            "empty_event_pair_ms": pair_ms,
+            "sum_of_kernel_ms_per_step": fwd_ms + upd_ms, "loop_ms_per_step": dt / args.steps * 1e3}
+    out["roofline"] = roof
+    if short_run is not None:
+        out["short_run"] = short_run
     if world > 1:
         dist.destroy_process_group()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(idx_np, y_np, CRITEO_SIZES)
         out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+    if world == 1 and not args.no_secondary and not args.loop_only:
+        # BASELINE configs[3] in the same line, so that the round-end run observes it: online DeepFM (3 x 256 MLP, SGD)
+        try:
+            del eng, table
+            torch.cuda.empty_cache()
+            sec = bench_deepfm(argparse.Namespace(steps=100, warmup=10, zipf=False), fmx, torch, dist, 1, 0, dev, False)
+            out["secondary"] = {"deepfm": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "mlp_section", "config")}}
+        except Exception as exc:                            # the headline line must not be lost to the secondary workload
+            out["secondary"] = {"deepfm": {"error": repr(exc)}}
     print(json.dumps(out))
 
 

@@ -469,6 +469,60 @@ struct FwdArgs {
   float inv_b;
 };
 
+// The part of the forward pass behind the row gather: field sums (butterfly over the lane groups), bi-interaction, logit,
+// loss and dlogit, stores.  s / ss / fo: this lane's partial sums of e, e*e and of the first-order terms over ITS fields.
+template <int LPR, int LAYOUT>
+__device__ __forceinline__ void forward_finish(const FwdArgs &a, const int b, const int lane, float4 s, float4 ss, float fo, bool bad,
+                                               const float y_early, const float bias0_early, const float bias1_early) {
+  const int q = lane % LPR;
+  const int kp = LPR * 4;
+  if (bad && a.out.error) *a.out.error = 1;
+
+  // field sums: butterfly over the slots (lanes with equal q), DPP / permlane exchanges (no LDS crossbar)
+#define FMX_BFLY(M)                               \
+  if (LPR <= M) {                                 \
+    s = s + xor_lane_f4<M>(s, lane);              \
+    ss = ss + xor_lane_f4<M>(ss, lane);           \
+    fo += xor_lane_f<M>(fo, lane);                \
+  }
+  FMX_BFLY(1) FMX_BFLY(2) FMX_BFLY(4) FMX_BFLY(8) FMX_BFLY(16) FMX_BFLY(32)
+#undef FMX_BFLY
+  const float4 bi = 0.5f * (s * s - ss);
+  float sbi = (bi.x + bi.y) + (bi.z + bi.w);
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) sbi += __shfl_xor(sbi, m);
+  // fo: lanes with q != 0 hold the sum of zeros; take the q == 0 value
+  fo = __shfl(fo, 0);
+
+  if (lane < LPR) {
+    if (a.out.S) *reinterpret_cast<float4 *>(a.out.S + (size_t)b * a.ldS + 4 * q) = s;
+    if (a.out.bi) *reinterpret_cast<float4 *>(a.out.bi + (size_t)b * kp + 4 * q) = bi;
+  }
+  if (lane == 0) {
+    float bias;
+    if (LAYOUT == FMX_LAYOUT_WEIGHTS) bias = bias0_early;
+    else bias = ftrl_w(bias0_early, bias1_early, a.h);
+    const float z = fo + sbi + bias;
+    if (a.out.sfirst) a.out.sfirst[b] = fo;
+    if (a.out.sbi) a.out.sbi[b] = sbi;
+    if (a.out.logit) a.out.logit[b] = z;
+    if (a.loss_kind != FMX_LOSS_NONE) {
+      const float y = y_early;
+      float loss, dz;
+      if (a.loss_kind == FMX_LOSS_BCE_LOGITS) {
+        loss = bcewl(z, y);
+        dz = (sigmoidf_(z) - y) * a.inv_b;
+      } else {
+        const float p = sigmoidf_(z);
+        loss = bcewl(p, y);
+        dz = (sigmoidf_(p) - y) * p * (1.f - p) * a.inv_b;
+      }
+      if (a.out.loss) a.out.loss[(size_t)b * a.ld1] = loss;
+      if (a.out.dz) a.out.dz[(size_t)b * a.ld1] = dz;
+    }
+  }
+}
+
 // NPASS > 0: the field loop is fully unrolled (F <= NPASS * SLOTS) and every index, value, offset and row load of the
 // sample is issued before the first use, so one wave keeps up to 3 * NPASS row requests in flight.  NPASS == 0: generic.
 template <int LPR, int LAYOUT, int NPASS>
@@ -481,6 +535,11 @@ __device__ __forceinline__ void forward_sample(const FwdArgs &a, const int b, co
   float4 s = splat(0.f), ss = splat(0.f);
   float fo = 0.f;
   bool bad = false;
+  // the label and the bias are only needed by lane 0's epilogue, but a load issued there is one more dependent round trip
+  // at the end of every wave: request them now, with the indices (every lane the same address: one request each)
+  const float y_early = a.loss_kind != FMX_LOSS_NONE ? a.y[b] : 0.f;
+  const float bias0_early = a.bias[0];
+  const float bias1_early = LAYOUT == FMX_LAYOUT_WEIGHTS ? 0.f : a.bias[1];
   const int n_outer = NPASS > 0 ? 1 : (a.F + SLOTS - 1) / SLOTS;
   for (int it = 0; it < n_outer; ++it) {
     uint32_t li[NP];
@@ -534,51 +593,7 @@ __device__ __forceinline__ void forward_sample(const FwdArgs &a, const int b, co
       }
     }
   }
-  if (bad && a.out.error) *a.out.error = 1;
-
-  // field sums: butterfly over the slots (lanes with equal q), DPP / permlane exchanges (no LDS crossbar)
-#define FMX_BFLY(M)                               \
-  if (LPR <= M) {                                 \
-    s = s + xor_lane_f4<M>(s, lane);              \
-    ss = ss + xor_lane_f4<M>(ss, lane);           \
-    fo += xor_lane_f<M>(fo, lane);                \
-  }
-  FMX_BFLY(1) FMX_BFLY(2) FMX_BFLY(4) FMX_BFLY(8) FMX_BFLY(16) FMX_BFLY(32)
-#undef FMX_BFLY
-  const float4 bi = 0.5f * (s * s - ss);
-  float sbi = (bi.x + bi.y) + (bi.z + bi.w);
-#pragma unroll
-  for (int m = 1; m < LPR; m <<= 1) sbi += __shfl_xor(sbi, m);
-  // fo: lanes with q != 0 hold the sum of zeros; take the q == 0 value
-  fo = __shfl(fo, 0);
-
-  if (lane < LPR) {
-    if (a.out.S) *reinterpret_cast<float4 *>(a.out.S + (size_t)b * a.ldS + 4 * q) = s;
-    if (a.out.bi) *reinterpret_cast<float4 *>(a.out.bi + (size_t)b * kp + 4 * q) = bi;
-  }
-  if (lane == 0) {
-    float bias;
-    if (LAYOUT == FMX_LAYOUT_WEIGHTS) bias = a.bias[0];
-    else bias = ftrl_w(a.bias[0], a.bias[1], a.h);
-    const float z = fo + sbi + bias;
-    if (a.out.sfirst) a.out.sfirst[b] = fo;
-    if (a.out.sbi) a.out.sbi[b] = sbi;
-    if (a.out.logit) a.out.logit[b] = z;
-    if (a.loss_kind != FMX_LOSS_NONE) {
-      const float y = a.y[b];
-      float loss, dz;
-      if (a.loss_kind == FMX_LOSS_BCE_LOGITS) {
-        loss = bcewl(z, y);
-        dz = (sigmoidf_(z) - y) * a.inv_b;
-      } else {
-        const float p = sigmoidf_(z);
-        loss = bcewl(p, y);
-        dz = (sigmoidf_(p) - y) * p * (1.f - p) * a.inv_b;
-      }
-      if (a.out.loss) a.out.loss[(size_t)b * a.ld1] = loss;
-      if (a.out.dz) a.out.dz[(size_t)b * a.ld1] = dz;
-    }
-  }
+  forward_finish<LPR, LAYOUT>(a, b, lane, s, ss, fo, bad, y_early, bias0_early, bias1_early);
 }
 
 template <int LPR, int LAYOUT, int NPASS>
@@ -621,11 +636,19 @@ constexpr int LEAD_NONE = 0, LEAD_CLOSES = 1, LEAD_THROUGH = 2;
 // deterministic block reduction of src[0..n): every thread sums a strided set of elements (16-byte groups when dense),
 // 16 independent loads in flight per round -- at B = 16,384 with 128 threads a 4-deep unroll left 32 dependent rounds of
 // HBM latency per sum and the one workgroup that owns the bias became the longest path of the launch -- then an LDS tree.
-// The order of the additions depends only on (n, ld == 1, blockDim).
+// The order of the additions depends only on (n, ld == 1, min(blockDim, 128)): at most 128 threads take part, so that
+// the 256-thread workgroups of the fused step launch and the default 128-thread ones of k_fm_update give identical bits.
 __device__ float block_sum(const float *src, int n, int ld, float *sm) {
   constexpr int U = 16;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x < 128 ? blockDim.x : 128;
   float acc = 0.f;
+  if (tid >= nt) {  // bystanders of a wider workgroup: only the barriers
+    __syncthreads();
+    for (int w = nt >> 1; w > 0; w >>= 1) __syncthreads();
+    const float r = sm[0];
+    __syncthreads();
+    return r;
+  }
   if (ld == 1) {
     const int n4 = n >> 2;
     const float4 *src4 = reinterpret_cast<const float4 *>(src);
@@ -663,7 +686,21 @@ __device__ float block_sum(const float *src, int n, int ld, float *sm) {
   return r;
 }
 
-template <int LAYOUT, int RULE>
+// WT: write-through (sc1) stores -- the fused step launch hands the updated rows to the next batch's forward waves of the
+// same launch, which read them with sc1 loads (MI355X_MICROARCH.md, "Valid forms": sc1 on both sides, the storing wave's
+// s_waitcnt vmcnt(0) before it signals)
+template <bool WT>
+__device__ __forceinline__ void st16(float *p, float4 v) {
+  if (WT) st_sc1_4(p, v);
+  else *reinterpret_cast<float4 *>(p) = v;
+}
+template <bool WT>
+__device__ __forceinline__ void st4(float *p, float v) {
+  if (WT) st_sc1(p, v);
+  else *p = v;
+}
+
+template <int LAYOUT, int RULE, bool WT = false>
 __device__ void bias_and_loss(const UpdArgs &a) {
   __shared__ float sm[256];
   const float db = block_sum(a.dz_first, a.B, a.ld1, sm);
@@ -671,13 +708,13 @@ __device__ void bias_and_loss(const UpdArgs &a) {
   if (a.loss_b && a.loss_out) ls = block_sum(a.loss_b, a.B, a.ld1, sm);
   if (threadIdx.x == 0) {
     if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
-      a.bias[0] = apply_rule<RULE>(a.bias[0], db, a.h);
+      st4<WT>(a.bias, apply_rule<RULE>(a.bias[0], db, a.h));
     } else {
       float z = a.bias[0], n = a.bias[1];
       const float w = ftrl_w(z, n, a.h);
       ftrl_upd(z, n, w, db, a.h);
-      a.bias[0] = z;
-      a.bias[1] = n;
+      st4<WT>(a.bias, z);
+      st4<WT>(a.bias + 1, n);
     }
     if (a.loss_b && a.loss_out) {
       int i = 0;
@@ -718,29 +755,30 @@ __device__ __forceinline__ RowRegs load_row(const float *rp, int q, int kp, int 
 }
 
 // gradient of the row from the run sums (dV = cV - V * cA, dw = cw), one application of the rule, store
-template <int LAYOUT, int RULE>
+template <int LAYOUT, int RULE, bool WT = false>
 __device__ __forceinline__ void update_row(float *rp, int q, int kp, int zoff, RowRegs r, float4 cV, float4 cA, float cw,
                                            const fmx_hyper_t &h) {
   // two roundings on purpose (no fma): where a sample is the row's only contribution to S (x = 1), cV = dz * V and
   // V * cA = V * dz round alike and the gradient is exactly 0, as in the reference's dz * x * (S - e)
   const float4 gr = cV - r.v * cA;
   if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
-    *reinterpret_cast<float4 *>(rp + 4 * q) = apply_rule4<RULE>(r.v, gr, h);
-    if (q == 0) rp[kp] = apply_rule<RULE>(r.fo.x, cw, h);
+    st16<WT>(rp + 4 * q, apply_rule4<RULE>(r.v, gr, h));
+    if (q == 0) st4<WT>(rp + kp, apply_rule<RULE>(r.fo.x, cw, h));
   } else {
     float4 z4 = r.z, n4 = r.n;
     ftrl_upd(z4.x, n4.x, r.v.x, gr.x, h);
     ftrl_upd(z4.y, n4.y, r.v.y, gr.y, h);
     ftrl_upd(z4.z, n4.z, r.v.z, gr.z, h);
     ftrl_upd(z4.w, n4.w, r.v.w, gr.w, h);
+    // the (z, n) half is read by nobody but the next update of this row (a later launch): plain stores
     *reinterpret_cast<float4 *>(rp + zoff + 4 * q) = z4;
     *reinterpret_cast<float4 *>(rp + zoff + kp + 4 * q) = n4;
-    *reinterpret_cast<float4 *>(rp + 4 * q) = ftrl_w4(z4, n4, h);
+    st16<WT>(rp + 4 * q, ftrl_w4(z4, n4, h));
     if (q == 0) {
       float4 fo = r.fo;
       ftrl_upd(fo.y, fo.z, fo.x, cw, h);
       fo.x = ftrl_w(fo.y, fo.z, h);
-      *reinterpret_cast<float4 *>(rp + kp) = fo;
+      st16<WT>(rp + kp, fo);
     }
   }
 }
@@ -773,23 +811,22 @@ template <> struct CoefA<false> {
 // walks EPG = 64 / SLOTS CONSECUTIVE occurrences sequentially, so duplicates inside a group are summed in registers;
 // one segmented scan over the SLOTS groups (log2(SLOTS) steps of wave shuffles) carries the sums of runs that span
 // groups.  At the tail of a run: the row update when the run began in this tile, a partial record otherwise.
-template <int LPR, int LAYOUT, int RULE, bool HAS_GBI, bool INL>
-__global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
-  __builtin_amdgcn_s_setprio(3);  // ahead of the side-stream sort's waves at the CU's instruction arbiter
+template <int LPR, int LAYOUT, int RULE, bool HAS_GBI, bool INL, bool WT>
+__device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   constexpr int SLOTS = WAVE / LPR;  // lane groups
   constexpr int EPG = LPR;           // consecutive occurrences per group
   constexpr int REC = 2 * LPR * 4 + 4;
   constexpr bool PREFETCH_ROWS = EPG <= 4;
   using CA = CoefA<HAS_GBI>;
-  if (blockIdx.x == 0) {  // the first block (dispatched first) owns the bias and the loss reduction
-    bias_and_loss<LAYOUT, RULE>(a);
+  if (blk == 0) {  // the first block (dispatched first) owns the bias and the loss reduction
+    bias_and_loss<LAYOUT, RULE, WT>(a);
     return;
   }
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, q = lane % LPR;
   const int kp = LPR * 4;
   const int tiles_per_field = a.Bp >> 6;
-  const int gt = (blockIdx.x - 1) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int gt = (blk - 1) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (gt >= a.F * tiles_per_field) return;
   const int f = gt / tiles_per_field;
   const int base = (gt - f * tiles_per_field) << 6;
@@ -841,6 +878,13 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
         row[j] = load_row<LAYOUT>(a.rows + (row0 + k[j]) * (size_t)a.stride, q, kp, a.zoff);
     }
   }
+  // INL: the row of the run that comes in from the previous tile (updated by THIS wave if the run ends here, by nobody
+  // else in this launch) is requested now, with the other rows, instead of behind this wave's own stores
+  RowRegs row_in;
+  row_in.v = row_in.z = row_in.n = row_in.fo = splat(0.f);
+  const bool run_comes_in = INL && base > 0 && val[0] && k[0] == tile_prevkey;  // meaningful in lane group 0
+  if (INL && slot == 0 && run_comes_in)
+    row_in = load_row<LAYOUT>(a.rows + (row0 + tile_prevkey) * (size_t)a.stride, q, kp, a.zoff);
   float4 cV[EPG];
   CA cA[EPG];
   float cw[EPG];
@@ -953,6 +997,9 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   }
 
   // ---- pass 2: walk the occurrences again; at the tail of a run apply the update or leave a partial ----
+  float4 leadV = splat(0.f), leadA = splat(0.f);  // INL: this tile's part of the run that came in and ends here
+  float leadw = 0.f;
+  bool have_lead = false;
 #pragma unroll
   for (int j = 0; j < EPG; ++j) {
     if (j > 0 && k[j] != k[j - 1]) {
@@ -967,12 +1014,18 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
       if (k[j] != tile_prevkey) {
         float *rp = a.rows + (row0 + k[j]) * (size_t)a.stride;
         const RowRegs r = PREFETCH_ROWS ? row[PREFETCH_ROWS ? j : 0] : load_row<LAYOUT>(rp, q, kp, a.zoff);
-        update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, accV, accA.vec(), accw, a.h);
+        update_row<LAYOUT, RULE, WT>(rp, q, kp, a.zoff, r, accV, accA.vec(), accw, a.h);
       } else {
-        // the run that came in from the previous tile ends here: its part inside this tile (read back by this wave's
-        // combine below, or by k_fm_fixup)
-        if (INL) store_part_sc1(part, q, kp, accV, accA.vec(), accw);
-        else store_part(part, q, kp, accV, accA.vec(), accw);
+        // the run that came in from the previous tile ends here: its part inside this tile stays in registers for this
+        // wave's combine below (INL), or goes to memory for k_fm_fixup
+        if (INL) {
+          leadV = accV;
+          leadA = accA.vec();
+          leadw = accw;
+          have_lead = true;
+        } else {
+          store_part(part, q, kp, accV, accA.vec(), accw);
+        }
       }
     }
   }
@@ -980,11 +1033,13 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   // ---- in-launch hand-off (INL): the CLOSING tile of a run sums the records of the tiles before it (they were
   //      dispatched earlier and wait on nothing) and applies the row update -- no second launch ----
   if (lead_state != LEAD_CLOSES) return;  // wave-uniform
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own lead record (read back below) is acknowledged
   const int t = gt - f * tiles_per_field;
   float *rp = a.rows + (row0 + tile_prevkey) * (size_t)a.stride;
-  RowRegs r;
-  if (lane < LPR) r = load_row<LAYOUT>(rp, q, kp, a.zoff);  // the row is final until this wave writes it
+  const RowRegs r = row_in;  // lanes < LPR: requested at the top (the row is final until this wave writes it)
+  // this tile's own part of the run: from the registers of the lane group that closed it to every lane group's lane q
+  const int src0 = __ffsll((long long)__ballot(have_lead)) - 1;  // first lane of that group (q == 0)
+  const float4 ownV = shfl4(leadV, src0 + q), ownA = shfl4(leadA, src0 + q);
+  const float ownw = __shfl(leadw, src0);
   // distance m to the head tile: tiles t-1, t-2, ... are THROUGH until the head (trail_state == 1)
   int m = 0;
   bool failed = false;
@@ -1023,10 +1078,16 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   float4 aV = splat(0.f), aA = splat(0.f);
   float aw = 0.f;
   for (int j = slot; j <= m; j += SLOTS) {
-    const float *rec = j == 0 ? a.parts + (gh * 2 + 1) * REC : a.parts + (gh + j) * 2 * REC;
-    aV = aV + ld_sc1_4(rec + 4 * q);
-    aA = aA + ld_sc1_4(rec + kp + 4 * q);
-    aw += ld_sc1(rec + 2 * kp);
+    if (j == m) {  // this tile's own record: the last one of its lane group, as in k_fm_fixup's order
+      aV = aV + ownV;
+      aA = aA + ownA;
+      aw += ownw;
+    } else {
+      const float *rec = j == 0 ? a.parts + (gh * 2 + 1) * REC : a.parts + (gh + j) * 2 * REC;
+      aV = aV + ld_sc1_4(rec + 4 * q);
+      aA = aA + ld_sc1_4(rec + kp + 4 * q);
+      aw += ld_sc1(rec + 2 * kp);
+    }
   }
 #pragma unroll
   for (int mm = LPR; mm < WAVE; mm <<= 1) {
@@ -1034,8 +1095,162 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
     aA = aA + shfl_xor4(aA, mm);
     aw += __shfl_xor(aw, mm);
   }
-  if (lane < LPR) update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, aV, aA, aw, a.h);
+  if (lane < LPR) update_row<LAYOUT, RULE, WT>(rp, q, kp, a.zoff, r, aV, aA, aw, a.h);
 }
+
+template <int LPR, int LAYOUT, int RULE, bool HAS_GBI, bool INL>
+__global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
+  __builtin_amdgcn_s_setprio(3);  // ahead of the side-stream sort's waves at the CU's instruction arbiter
+  update_body<LPR, LAYOUT, RULE, HAS_GBI, INL, false>(a, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_fm_fused: update(s) and forward(s + 1) in ONE launch (the online loop's steady state: one launch per step)
+// ------------------------------------------------------------------------------------------------------------
+// In the loop of fmx_fm_stream step s is forward(s) -> update(s), two dependent launches: ~7.5 + ~12 us of kernels whose
+// critical paths are chains of dependent round trips, plus two launch boundaries.  Here the blocks of update(s) come
+// first in the grid and the waves of forward(s + 1) behind them, FUSE_SPW samples per wave: a forward wave fetches its
+// indices and labels at once, then waits until every update wave of the launch has arrived at a counter (each after
+// its s_waitcnt vmcnt(0), i.e. with its row stores acknowledged), and only then gathers its rows -- with sc1 loads, the
+// update's row stores of this launch being write-through (sc1): the hand-off form of MI355X_MICROARCH.md "Valid forms"
+// (sc1 both sides, storing wave drained before it signals, one wave of the consumer workgroup polls relaxed and the
+// others load behind a workgroup barrier it then joins).  What is saved: a launch boundary, the forward's launch ramp
+// and its index round trip.  The arithmetic is that of k_fm_update and k_fm_forward: identical bits.
+// Progress: update waves wait for nothing but lower-numbered update tiles (the in-launch hand-off of crossing runs), so
+// they finish whatever the forward waves do; the grid is sized so that ALL of it is resident at once (host: occupancy
+// query), the wait is bounded (error flag 3), and workgroups are dispatched in index order.
+constexpr int FUSE_SHARDS = 16;  // arrival counters, each on a 128-byte line of its own
+constexpr int FUSE_SPW = 4;      // samples per forward wave
+struct FuseArgs {
+  uint32_t *done;        // [FUSE_SHARDS][32]: word 0 of every line counts arrivals; zeroed at the start of the stream call
+  uint32_t target;       // arrivals once the update workgroups of THIS launch are done: (fused launches so far + 1) * workgroups
+  uint32_t rows_bytes;   // size of the table (buffer loads range-check against it)
+  int32_t n_upd_blocks;
+  int32_t first_sleep, poll_sleep;  // in s_sleep units of 64 clocks: before the first poll, and between polls
+  int32_t debug;                    // timing experiments (wrong results): 4 workgroups arrive BEFORE their update, 5 no gather
+  unsigned long long *stamps;       // debug 6: [workgroup][4] s_memrealtime (100 MHz) at start / arrival or poll match / end
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int LPR, int LAYOUT, int RULE, int NPASS, int AUX>
+__global__ __launch_bounds__(1024, 4) void k_fm_fused(UpdArgs u, FwdArgs a, FuseArgs z) {  // 4 waves per SIMD: <= 128 VGPRs
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63;
+  if (z.stamps && threadIdx.x == 0) z.stamps[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
+  if ((int)blockIdx.x < z.n_upd_blocks) {
+    if (z.debug == 4 && threadIdx.x == 0)
+      (void)__hip_atomic_fetch_add(z.done + (blockIdx.x % FUSE_SHARDS) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    update_body<LPR, LAYOUT, RULE, false, true, true>(u, (int)blockIdx.x);
+    if (z.debug == 4) return;
+    // every store of every wave of the workgroup is acknowledged before the workgroup counts as done: one arrival per
+    // workgroup (a counter word takes ~90 atomics per microsecond; one per wave was 2,500 of them per launch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      (void)__hip_atomic_fetch_add(z.done + (blockIdx.x % FUSE_SHARDS) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (z.stamps) z.stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    return;
+  }
+  constexpr int SLOTS = WAVE / LPR, NP = NPASS, SPW = FUSE_SPW;
+  const int slot = lane / LPR, q = lane % LPR;
+  const int kp = LPR * 4;
+  const int b0 = (((int)blockIdx.x - z.n_upd_blocks) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) * SPW;
+  // ---- phase A (beside the update waves): everything that does not depend on the table ----
+  int64_t lo[NP];
+  uint32_t vocab[NP];
+  bool live[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int f = p * SLOTS + slot;
+    live[p] = f < a.F;
+    lo[p] = live[p] ? a.foff[f] : 0;
+    vocab[p] = live[p] ? (uint32_t)(a.foff[f + 1] - lo[p]) : 0u;
+  }
+  uint32_t li[SPW][NP];
+  float yv[SPW];
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const int b = b0 + i;
+    const bool valid = b < a.B;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) li[i][p] = (valid && live[p]) ? (uint32_t)a.idx[(size_t)b * a.F + p * SLOTS + slot] : 0u;
+    yv[i] = valid ? a.y[b] : 0.f;
+  }
+  // ---- wait for the update waves of this launch: wave 0 of the workgroup polls, the others wait at the barrier ----
+  if (threadIdx.x < 64) {
+    // the update takes several microseconds: no poll before that (every poll is a request to the counters' lines, which
+    // the arrivals need), then one poll per poll_sleep
+    for (int i = 0; i < z.first_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+    for (unsigned spin = 0;; ++spin) {
+      uint32_t c = lane < FUSE_SHARDS ? __hip_atomic_load(z.done + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+      for (int m = 1; m < FUSE_SHARDS; m <<= 1) c += __shfl_xor(c, m);
+      if (__shfl(c, 0) >= z.target) break;
+      if (spin >= (1u << 20)) {
+        if (lane == 0 && u.error) *u.error = 3;
+        break;
+      }
+      for (int i = 0; i < z.poll_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    if (z.stamps && threadIdx.x == 0) z.stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (AUX == 0 && threadIdx.x < 64) {
+    // ONE agent-scope acquire per workgroup, by the wave that polled: drops this CU's L1 lines (rows read before the
+    // update); the wait holds the barrier below until the invalidate has completed.  The gather then uses PLAIN loads, so
+    // the hot rows of the small fields -- read by thousands of samples -- are served by L1 / L2 (sc1 loads of every row go
+    // past the caches to the memory side, where 4,096 reads of one line queue up: 16 us instead of 3 for the gather)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  asm volatile("" ::: "memory");
+  // ---- phase B: the gather ----
+  const float bias0 = ld_sc1(a.bias);
+  const float bias1 = LAYOUT == FMX_LAYOUT_WEIGHTS ? 0.f : ld_sc1(a.bias + 1);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.rows), 0, (int)z.rows_bytes, 0x00020000);
+  float4 r0[SPW][NP];
+  float rw[SPW][NP];
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      r0[i][p] = splat(0.f);
+      rw[i][p] = 0.f;
+      if (b0 + i < a.B && live[p] && li[i][p] < vocab[p] && z.debug != 5) {
+        const uint32_t off = (uint32_t)(((size_t)(lo[p] + li[i][p]) * a.stride + 4 * q) * sizeof(float));
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX);  // aux 0 = plain (behind the acquire), 16 = sc1
+        r0[i][p] = {__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+        if (q == 0) rw[i][p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + kp * sizeof(float), 0, AUX));
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const int b = b0 + i;
+    if (b >= a.B) break;  // wave-uniform
+    float4 s = splat(0.f), ss = splat(0.f);
+    float fo = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (live[p]) {
+        if (li[i][p] < vocab[p]) {
+          const float4 e = 1.f * r0[i][p];  // x == 1 (fmx_fm_stream has no feature values)
+          s = s + e;
+          ss = ss + e * e;
+          fo += rw[i][p] * 1.f;
+        } else {
+          bad = true;
+        }
+      }
+    }
+    forward_finish<LPR, LAYOUT>(a, b, lane, s, ss, fo, bad, yv[i], bias0, bias1);
+  }
+  if (z.stamps && threadIdx.x == 0) z.stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+}
+
 
 // ------------------------------------------------------------------------------------------------------------
 // k_fm_online: the reference's online protocol on a device-resident stream (pure FM)
@@ -1690,6 +1905,12 @@ struct Tune {
                          // launch (k_fm_fixup) instead of the in-launch hand-off; both give identical bits
   int online_persistent = 1;  // FMX_ONLINE_PERSISTENT=0 / fmx_set_option("online_persistent", 0): fmx_online_run_mlp as per-sample launches
   int sort_ahead = 8;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..8)
+  int fused_step = 0;    // FMX_FUSED_STEP=1 / fmx_set_option("fused_step", 1): fmx_fm_stream launches update(s) + forward(s + 1) as ONE
+                         // launch (k_fm_fused) instead of separately; identical bits; measured slower, so off
+  int fused_debug = 0;        // FMX_FUSED_DEBUG (timing experiments, wrong results): 1 no forward workgroups, 2 forward does not wait
+  int fused_wpb = 4;          // FMX_FUSED_WPB: waves per workgroup of k_fm_fused (4 or 16)
+  int fused_first_sleep = 64; // FMX_FUSED_FIRST_SLEEP: s_sleep units (64 clocks) a forward workgroup waits before its first poll
+  int fused_poll_sleep = 8;   // FMX_FUSED_POLL_SLEEP: s_sleep units between polls
   int sort_chunked = 1;  // FMX_SORT_CHUNKED / fmx_set_option("sort_chunked", v): 0: one workgroup per field (k_sort_occ) at
                          // every width; 1: k_sort_chunk + k_sort_merge from 8,192 composites per field on; 2: from 2,048 on.
                          // Identical lists either way
@@ -1704,6 +1925,11 @@ Tune &tune() {
     if (const char *e = getenv("FMX_ONLINE_PERSISTENT")) x.online_persistent = atoi(e);
     if (const char *e = getenv("FMX_INLINE_FIXUP")) x.inline_fixup = atoi(e);
     if (const char *e = getenv("FMX_SORT_CHUNKED")) x.sort_chunked = atoi(e);
+    if (const char *e = getenv("FMX_FUSED_STEP")) x.fused_step = atoi(e);
+    if (const char *e = getenv("FMX_FUSED_DEBUG")) x.fused_debug = atoi(e);
+    if (const char *e = getenv("FMX_FUSED_WPB")) x.fused_wpb = atoi(e) == 16 ? 16 : 4;
+    if (const char *e = getenv("FMX_FUSED_FIRST_SLEEP")) x.fused_first_sleep = atoi(e);
+    if (const char *e = getenv("FMX_FUSED_POLL_SLEEP")) x.fused_poll_sleep = atoi(e);
     auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
     if (!ok(x.wpb_fwd)) x.wpb_fwd = 2;
     if (!ok(x.wpb_upd)) x.wpb_upd = 2;
@@ -1721,8 +1947,10 @@ struct Workspace {
   size_t sorted_stride;
   uint32_t *runs;         // SORT_AHEAD_MAX buffers of the same shape: the chunk-sorted intermediate of k_sort_chunk / k_sort_merge
   int32_t *meta;
-  int32_t *counter;  // step counter of fmx_fm_stream (one int32 in its own 256-byte slot)
+  int32_t *counter;  // step counter (one int32 in its own 256-byte slot; unused by the current loop)
   float *parts;
+  uint32_t *done;    // FUSE_SHARDS x 128 bytes: arrival counters of the fused step launch
+  float *fwd2;       // [B, kp] S | [B] dz | [B] loss: the second set of forward outputs of the fused loop (ping-pong)
   size_t bytes;
 };
 
@@ -1746,7 +1974,11 @@ Workspace carve(const fmx_table_t *t, int B, void *base) {
   w.meta = reinterpret_cast<int32_t *>(p + o_meta);
   w.counter = reinterpret_cast<int32_t *>(p + o_counter);
   w.parts = reinterpret_cast<float *>(p + o_parts);
-  w.bytes = o_parts + align_up(F * tiles * 2 * rec * 4, 256);
+  const size_t o_done = o_parts + align_up(F * tiles * 2 * rec * 4, 256);
+  const size_t o_fwd2 = o_done + (size_t)FUSE_SHARDS * 128;
+  w.done = reinterpret_cast<uint32_t *>(p + o_done);
+  w.fwd2 = reinterpret_cast<float *>(p + o_fwd2);
+  w.bytes = o_fwd2 + align_up(((size_t)B * t->kp + 2 * align_up((size_t)B, 4)) * 4, 256);
   return w;
 }
 
@@ -1858,6 +2090,78 @@ void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st
   if (has_gbi) launch_update<LPR, true, false>(a, rule, st);
   else launch_update<LPR, false, false>(a, rule, st);
   launch_fixup<LPR>(a, rule, st);
+}
+
+// k_fm_fused is built for the kp = 16 row (4 lanes per row) and up to 64 fields; -1: not eligible.  Otherwise the number of
+// forward workgroups of a launch; the whole grid must be resident at once (see the kernel's comment).
+using FusedFn = void (*)(UpdArgs, FwdArgs, FuseArgs);
+template <int AUX>
+FusedFn fused_kernel_aux(int rule, int np) {
+  switch (rule) {
+    case FMX_RULE_SIGNADAM:
+      switch (np) {
+        case 1: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, 1, AUX>;
+        case 2: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, 2, AUX>;
+        case 3: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, 3, AUX>;
+        default: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, 4, AUX>;
+      }
+    case FMX_RULE_SGD:
+      switch (np) {
+        case 1: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, 1, AUX>;
+        case 2: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, 2, AUX>;
+        case 3: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, 3, AUX>;
+        default: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, 4, AUX>;
+      }
+    default:
+      switch (np) {
+        case 1: return k_fm_fused<4, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, 1, AUX>;
+        case 2: return k_fm_fused<4, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, 2, AUX>;
+        case 3: return k_fm_fused<4, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, 3, AUX>;
+        default: return k_fm_fused<4, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, 4, AUX>;
+      }
+  }
+}
+// fused_step 1: one agent acquire per forward workgroup + plain gather loads (default); 2: sc1 gather loads, no acquire
+FusedFn fused_kernel(int rule, int np) { return tune().fused_step == 2 ? fused_kernel_aux<16>(rule, np) : fused_kernel_aux<0>(rule, np); }
+
+// Is the one-launch step usable for this table and batch on the current device?  (kp = 16, <= 64 fields, a table the
+// 32-bit buffer offsets reach, the in-launch hand-off enabled, and the WHOLE grid resident at once.)
+bool fused_eligible(const fmx_table_t *table, int32_t B, int rule, hipStream_t st) {
+  if (!tune().fused_step || !tune().inline_fixup || is_capturing(st)) return false;
+  if (table->kp != 16 || table->n_fields > 64 || B < OVERLAP_MIN_BATCH) return false;
+  if ((uint64_t)table->n_rows * (uint64_t)table->row_stride * 4ull >= (1ull << 32)) return false;
+  const int np = (table->n_fields + 15) / 16;
+  const int tiles = table->n_fields * (fmx_sorted_width(B) >> 6);
+  const int wpb = tune().fused_wpb;
+  const int n_blocks = 1 + (tiles + wpb - 1) / wpb + (B + wpb * FUSE_SPW - 1) / (wpb * FUSE_SPW);
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(fused_kernel(rule, np)), 64 * wpb, 0) != hipSuccess)
+    return false;
+  // (register-limited at 4 workgroups per CU, where the occupancy query is exact: MI355X_MICROARCH.md, "Residency")
+  return (long long)n_blocks <= (long long)cus * per_cu;
+}
+
+int fused_impl(const fmx_table_t *table, int rule, const UpdArgs &u, const FwdArgs &f, const Workspace &w, uint32_t launches_before,
+               hipStream_t st, unsigned long long *stamps = nullptr) {
+  const int np = (table->n_fields + 15) / 16;
+  const int tiles = u.F * (u.Bp >> 6);
+  const int wpb = tune().fused_wpb;
+  FuseArgs z;
+  z.done = w.done;
+  z.n_upd_blocks = 1 + (tiles + wpb - 1) / wpb;
+  z.target = (launches_before + 1u) * (uint32_t)z.n_upd_blocks;
+  z.rows_bytes = (uint32_t)((uint64_t)table->n_rows * (uint64_t)table->row_stride * 4ull);
+  z.first_sleep = tune().fused_first_sleep;
+  z.poll_sleep = tune().fused_poll_sleep;
+  z.debug = tune().fused_debug;
+  z.stamps = stamps;
+  int n_fwd = (f.B + wpb * FUSE_SPW - 1) / (wpb * FUSE_SPW);
+  if (tune().fused_debug == 1) n_fwd = 0;      // timing experiments only (results are wrong): the update part alone
+  if (tune().fused_debug == 2) z.target = 0;   // ... the forward part does not wait
+  hipLaunchKernelGGL(fused_kernel(rule, np), dim3(z.n_upd_blocks + n_fwd), dim3(64 * wpb), 0, st, u, f, z);
+  return check_launch("k_fm_fused");
 }
 
 template <int E>
@@ -2125,6 +2429,7 @@ int fmx_set_option(const char *name, int value) {
   else if (!strcmp(name, "sort_ahead")) slot = &t.sort_ahead;
   else if (!strcmp(name, "online_persistent")) slot = &t.online_persistent;
   else if (!strcmp(name, "sort_chunked")) slot = &t.sort_chunked;
+  else if (!strcmp(name, "fused_step")) slot = &t.fused_step;
   else return fail(FMX_ERR_ARG, "fmx_set_option: unknown option '%s'", name);
   const int old = *slot;
   *slot = value;
@@ -2225,7 +2530,7 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     // launch on the side stream while the previous group runs forward / update / fixup on `stream`.  Ring of
     // 2 * ahead sorted buffers; per group one sort launch and four event operations, so the host issues ~3.6 runtime
     // calls per step instead of 8 (at ~4 us each the per-batch version was host-bound).
-    Side *sd = (B >= OVERLAP_MIN_BATCH && n_steps > 0) ? side_for_current_device() : nullptr;
+    Side *sd = (B >= OVERLAP_MIN_BATCH && n_steps > 0 && tune().fused_debug != 3) ? side_for_current_device() : nullptr;  // debug 3: the sorts on `stream` itself
     hipStream_t user = st;
     const bool detour = sd && st == nullptr;  // the legacy default stream cannot be captured / is slow to enqueue on
     if (detour) {
@@ -2240,12 +2545,31 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
       }
       return r;
     };
-    (void)hipMemsetAsync(w.counter, 0, sizeof(int32_t), st);
     int ahead = tune().sort_ahead;
     if (ahead < 1) ahead = 1;
     if (ahead > SORT_AHEAD_MAX) ahead = SORT_AHEAD_MAX;
-    auto sort_group = [&](int g, int first_step, hipStream_t where) -> int {  // steps [first_step, first_step + n)
-      const int n = (n_steps - first_step) < ahead ? (n_steps - first_step) : ahead;
+    // ---- the one-launch step (k_fm_fused) where the table, the batch and the device allow it ----
+    const bool fused = n_steps > 1 && fwd->sample_ld == 0 && fused_eligible(table, B, rule, st);
+    uint32_t n_fused = 0;
+    fmx_fwd_out_t alt = *fwd;  // the second set of forward outputs lives in the workspace
+    alt.S = w.fwd2;
+    alt.dz = w.fwd2 + (size_t)B * table->kp;
+    alt.loss = alt.dz + align_up((size_t)B, 4);
+    alt.bi = alt.first = alt.sfirst = alt.sbi = alt.logit = nullptr;
+    fmx_fwd_out_t mine = *fwd;
+    mine.bi = mine.first = mine.sfirst = mine.sbi = mine.logit = nullptr;
+    auto fwd_set = [&](int s) -> const fmx_fwd_out_t * { return ((n_steps - 1 - s) & 1) ? &alt : &mine; };
+    if (fused) (void)hipMemsetAsync(w.done, 0, (size_t)FUSE_SHARDS * 128, st);
+    // group g holds min(2^g, ahead) batches: the first sort (one batch) runs beside the first forward pass and exposes only
+    // its own ~19 us instead of a whole group's 30; the pipeline is at full depth from the fourth group on.  Group g uses
+    // half (g & 1) of the ring of 2 * ahead sorted buffers.
+    auto group_size = [&](int g, int first_step) {
+      int n = g < 3 ? (1 << g) : ahead;
+      if (n > ahead) n = ahead;
+      if (n > n_steps - first_step) n = n_steps - first_step;
+      return n;
+    };
+    auto sort_group = [&](int g, int first_step, int n, hipStream_t where) -> int {  // steps [first_step, first_step + n)
       SortBatch mb;
       mb.n_pool = n_pool;
       mb.first = first_step % n_pool;
@@ -2254,37 +2578,60 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
       mb.sorted_stride = (int64_t)w.sorted_stride;
       return sort_impl(table, idx_pool, B, w.sorted + (size_t)(g & 1) * ahead * w.sorted_stride, w.runs, fwd->error, where, &mb);
     };
-    const int n_groups = (n_steps + ahead - 1) / ahead;
-    if (sd && n_groups > 0) {
+    if (sd && n_steps > 0) {
       (void)hipEventRecord(sd->fork, st);
       (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
-      rc = sort_group(0, 0, sd->stream);
+      rc = sort_group(0, 0, group_size(0, 0), sd->stream);
       (void)hipEventRecord(sd->sorted[0], sd->stream);
     }
-    for (int g = 0; g < n_groups && rc == FMX_OK; ++g) {
-      const int first_step = g * ahead;
-      const int n = (n_steps - first_step) < ahead ? (n_steps - first_step) : ahead;
+    int first_step = 0;
+    for (int g = 0; first_step < n_steps && rc == FMX_OK; ++g) {
+      const int n = group_size(g, first_step);
+      const int next_first = first_step + n;
       if (sd) {
-        if (g + 1 < n_groups) {  // sort the next group while this one runs
+        if (next_first < n_steps) {  // sort the next group while this one runs
           if (g >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[(g + 1) & 1], 0);  // group g-1 is done with that half
-          rc = sort_group(g + 1, first_step + ahead, sd->stream);
+          rc = sort_group(g + 1, next_first, group_size(g + 1, next_first), sd->stream);
           (void)hipEventRecord(sd->sorted[(g + 1) & 1], sd->stream);
         }
       } else {
-        rc = sort_group(g, first_step, st);
+        rc = sort_group(g, first_step, n, st);
       }
       for (int i = 0; i < n && rc == FMX_OK; ++i) {
         const int s = first_step + i, j = s % n_pool;
         const int32_t *idx = idx_pool + (size_t)j * B * F;
         const float *y = y_pool + (size_t)j * B;
         const uint32_t *sorted = w.sorted + ((size_t)(g & 1) * ahead + i) * w.sorted_stride;
-        rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
+        if (!fused) {
+          rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
+          if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
+          if (rc == FMX_OK)
+            rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
+                             loss_out ? loss_out + s : nullptr, st, nullptr, fwd->sample_ld, fwd->error);
+          continue;
+        }
+        // one launch per step: update(s) + forward(s + 1) (k_fm_fused); the forward outputs ping-pong between the caller's
+        // buffers and the workspace's second set, the LAST step using the caller's
+        const fmx_fwd_out_t *cur = fwd_set(s), *nxt = fwd_set(s + 1);
+        if (s == 0) rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, cur, st);
         if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
-        if (rc == FMX_OK)
-          rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                           loss_out, st, loss_out ? w.counter : nullptr, fwd->sample_ld, fwd->error);
+        if (rc != FMX_OK) break;
+        const UpdArgs ua = fill_upd(table, hyper, w, sorted, nullptr, cur->S, cur->dz, cur->dz, nullptr, B, cur->loss, inv_b,
+                                    loss_out ? loss_out + s : nullptr, nullptr, cur->sample_ld, fwd->error);
+        if (s + 1 < n_steps) {
+          const int jn = (s + 1) % n_pool;
+          const FwdArgs fa = fill_fwd(table, hyper, idx_pool + (size_t)jn * B * F, nullptr, y_pool + (size_t)jn * B, B, loss_kind, inv_b, nxt);
+          // debug 6 (tools/fused_stamps.py): the caller's loss buffer is followed by room for the launch's time stamps
+          unsigned long long *stamps = (tune().fused_debug == 6 && loss_out)
+                                           ? reinterpret_cast<unsigned long long *>(loss_out + (((size_t)n_steps + 63) & ~(size_t)63)) : nullptr;
+          rc = fused_impl(table, rule, ua, fa, w, n_fused++, st, stamps);
+        } else {
+          launch_update_pair<4>(ua, rule, false, st);
+          rc = check_launch("k_fm_update");
+        }
       }
       if (sd) (void)hipEventRecord(sd->consumed[g & 1], st);
+      first_step = next_first;
     }
     return rejoin(rc);
   }
