@@ -215,6 +215,45 @@ def bench_online(args, torch):
         "all_classes": rates, "vs_baseline_all": {k: rates[k] / PUBLISHED_ONLINE[k] for k in rates}}))
 
 
+def bench_class_surface(torch, n_steps=40):
+    """Mini-batch rate THROUGH THE DROP-IN CLASS (FMAdam.update_embedding, B = 4096, Criteo vocabulary, k = 16, the reference's
+    rule): nested lists as the reference takes them (reference fm_adam.py:35-36 converts them per call, and so must we) against
+    the array path fed by utils.data_preprocess.PinnedBatchStager (pinned int32 [B, 39], non-blocking copies, double-buffered)."""
+    from models.models_online_deep.fm_adam import FMAdam
+    from utils.data_preprocess import PinnedBatchStager
+    rng = np.random.default_rng(5)
+    N = BATCH * 8
+    index = np.stack([rng.integers(0, s, size=N) for s in CRITEO_SIZES], axis=1).astype(np.int32)
+    label = (rng.uniform(size=N) < 0.3).astype(np.int64)
+    torch.manual_seed(0)
+    m = FMAdam(CRITEO_SIZES, embedding_size=K_EMB, n=1e-4)
+    m.strict_index_check = False
+    out = {}
+    Xi, Xv, Y = index[:BATCH].tolist(), [[1] * F for _ in range(BATCH)], label[:BATCH].tolist()
+    m.update_embedding(Xi, Xv, Y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        m.update_embedding(Xi, Xv, Y)
+    torch.cuda.synchronize()
+    out["nested_lists_samples_per_s"] = 3 * BATCH / (time.perf_counter() - t0)
+    for _ in PinnedBatchStager(index, label, BATCH):       # warm-up pass (pinned buffers, streams)
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while n < n_steps:
+        for idx_d, xv_d, y_d in PinnedBatchStager(index, label, BATCH):
+            m.update_embedding(idx_d, xv_d, y_d)
+            n += 1
+    m.check_index_flag()
+    torch.cuda.synchronize()
+    out["pinned_arrays_samples_per_s"] = n * BATCH / (time.perf_counter() - t0)
+    out["note"] = ("FMAdam.update_embedding at B = 4096 through the Python class; host memcpy into pinned memory + H2D copy + the "
+                   "step inside the timed region; one fmx_fm_step call (3 launches) per batch, Python-bound")
+    return out
+
+
 def stream_read_probe(fmx, torch, dev):
     """HBM-read ceiling on this GPU, same run: 16-byte loads over a 4 GiB buffer (fmx_stream_read), 5 timed passes."""
     probe = torch.empty(1 << 30, dtype=torch.float32, device=dev)      # 4 GiB
@@ -462,6 +501,11 @@ def main():
         # BASELINE configs[3] in the same line, so that the round-end run observes it: online DeepFM (3 x 256 MLP, SGD)
         try:
             del eng, table
+            torch.cuda.empty_cache()
+            out["class_surface"] = bench_class_surface(torch)
+        except Exception as exc:
+            out["class_surface"] = {"error": repr(exc)}
+        try:
             torch.cuda.empty_cache()
             sec = bench_deepfm(argparse.Namespace(steps=100, warmup=10, zipf=False), fmx, torch, dist, 1, 0, dev, False)
             out["secondary"] = {"deepfm": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "mlp_section", "config")}}

@@ -39,6 +39,15 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+class HandOffTimeout(RuntimeError):
+    """Device error word 2 (k_fm_update: a crossing run's row update was skipped) or 3 (k_fm_fused: the forward may have read
+    stale rows): an in-launch hand-off ran into its spin bound.  Never observed; the table must be considered corrupt."""
+
+    def __init__(self, code):
+        super().__init__(f"fmx: in-launch hand-off timed out (device error word {code}); the table is not the exact result")
+        self.code = code
+
+
 class FMEngine:
     def __init__(self, table: FlatTable, max_batch=4096):
         if not torch.cuda.is_available():
@@ -290,6 +299,11 @@ class FMEngine:
         return self._mlp_loss, self._mlp_dz, self._mlp_gbi
 
     def check_error_flag(self):
-        if int(self.error.item()) != 0:
+        """The device-side error word (include/fmx.h, Conventions): 1 -> IndexError like nn.Embedding; 2 / 3 -> HandOffTimeout
+        (an in-launch hand-off ran into its spin bound: the table is no longer the exact result).  Synchronises."""
+        code = int(self.error.item())
+        if code != 0:
             self.error.zero_()
-            raise IndexError("index out of range in self (flagged by the fmx kernels)")
+            if code == 1:
+                raise IndexError("index out of range in self (flagged by the fmx kernels)")
+            raise HandOffTimeout(code)

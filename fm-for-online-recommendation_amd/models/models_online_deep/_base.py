@@ -211,12 +211,59 @@ class OnlineFMBase(nn.Module):
     # forward pieces (reference deepfm_adam.py:46-89)
     # ------------------------------------------------------------------------------------------------------
     def _inputs(self, Xi, Xv, Y=None):
+        """-> (idx int32 [B, F], xv fp32 [B, F] or None when every value is 1, y fp32 [B] or None), all on the device.
+        Nested lists (the reference's convention, fm_adam.py:35-36) are converted and range-checked on the host.  Arrays
+        and tensors take the fast path: no list conversion; a CUDA tensor is used where it lies (int32 contiguous: as is),
+        Xv may be None (all ones); the range check is the kernels' (strict_index_check: the flag is read after the step,
+        one small device-to-host copy; set it to False to leave the stream asynchronous and call check_index_flag())."""
+        if torch.is_tensor(Xi) or isinstance(Xi, np.ndarray):
+            return self._inputs_fast(Xi, Xv, Y)
         idx, xv = fmx.normalize_inputs(Xi, Xv, self.field_size, self.feature_sizes)
         return self._engine.to_device(idx, xv, Y)
+
+    strict_index_check = True
+
+    def _inputs_fast(self, Xi, Xv, Y):
+        dev, F = self.device, self.field_size
+
+        def to_dev(a, dtype):
+            if a is None:
+                return None
+            t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+            if not t.is_cuda:
+                if t.dtype != dtype:
+                    t = t.to(dtype)
+                t = t.contiguous()
+                t = (t.pin_memory() if not t.is_pinned() else t).to(dev, non_blocking=True)
+            elif t.dtype != dtype:
+                t = t.to(dtype)
+            return t.contiguous()
+        idx_d = to_dev(Xi, torch.int32).reshape(-1, F)
+        xv_d = to_dev(Xv, torch.float32)
+        if xv_d is not None:
+            xv_d = xv_d.reshape(-1, F)
+            if xv_d.shape != idx_d.shape:
+                raise ValueError(f"Xi {tuple(idx_d.shape)} and Xv {tuple(xv_d.shape)} disagree")
+        y_d = to_dev(Y, torch.float32)
+        if y_d is not None:
+            y_d = y_d.reshape(-1)
+        self._fast_inputs_pending = True
+        return idx_d, xv_d, y_d
+
+    def check_index_flag(self):
+        """Raise IndexError if a kernel met an index outside its field since the last check (array / tensor inputs are
+        range-checked on the device; nested lists on the host, before anything is launched)."""
+        self._fast_inputs_pending = False
+        self._engine.check_error_flag()
+
+    def _after_step(self):
+        if getattr(self, "_fast_inputs_pending", False) and self.strict_index_check:
+            self.check_index_flag()
 
     def _fm_forward(self, Xi, Xv):
         idx_d, xv_d, _ = self._inputs(Xi, Xv)
         B = self._engine.forward(self._hyper, idx_d, xv_d)
+        self._after_step()
         return B
 
     def first_order(self, Xi, Xv):
@@ -277,7 +324,9 @@ class OnlineFMBase(nn.Module):
         if y_d.numel() != idx_d.shape[0]:
             raise ValueError(f"Target size ({y_d.numel()}) must be the same as input size ({idx_d.shape[0]})")
         self._engine.step(self._hyper, self.update_rule, loss_kind, idx_d, xv_d, y_d)
-        return self._engine.loss_out[0].clone()
+        out = self._engine.loss_out[0].clone()
+        self._after_step()
+        return out
 
     def update_embedding(self, Xi, Xv, Y):
         """One mini-batch step on forward_fm (reference fm_adam.py:56-69); returns the loss tensor."""
@@ -285,6 +334,10 @@ class OnlineFMBase(nn.Module):
         return self._fm_step(Xi, Xv, Y, self._loss_update_embedding)
 
     def fit(self, Xi, Xv, Y):
+        self._fit(Xi, Xv, Y)
+        self._after_step()
+
+    def _fit(self, Xi, Xv, Y):
         self.train()
         if not self._has_mlp:
             self._fm_step(Xi, Xv, Y, self._loss_fit)

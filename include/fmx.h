@@ -7,13 +7,28 @@
  * INTEGRATION.md shows the stub a reference maintainer would add.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer into caller-owned memory unless the comment says "host";
- *     nothing is allocated, freed or retained by the library;
- *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no implicit
- *     synchronisation, and is safe to capture into a hipGraph (fmx_fm_stream with timing excepted);
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless the comment says "host".  The data path allocates
+ *     nothing: tables, batches, outputs and the per-step workspace (fmx_workspace_bytes) are the caller's.  What the library
+ *     DOES own, per process: (a) per device, created on first use and never destroyed, two non-blocking HIP streams (one for
+ *     the occurrence sorts that run beside the steps, one that stands in for the legacy default stream) and a handful of
+ *     timing-disabled events ordering them against `stream`; (b) the tuning switches of fmx_set_option (process-wide, read
+ *     by every call); (c) a launch sequence counter tagging the in-launch hand-offs; (d) fmx_fm_stream's MEASURING mode
+ *     (kernel_ms != null) alone creates its HIP events and one temporary device buffer per call and frees them before it
+ *     returns -- it synchronises the stream and is a benchmark facility, not part of the data path;
+ *   - every other call is asynchronous on `stream` (a hipStream_t passed as void*) and performs no implicit
+ *     synchronisation; work the library puts on its own streams is ordered behind what `stream` held at the call and
+ *     `stream` is ordered behind it before the call returns.  Calls are safe to capture into a hipGraph except fmx_fm_stream
+ *     (cross-stream events, optional timing); a capturing stream takes the paths without in-launch hand-offs;
  *   - return value: 0 on success, a negative fmx_status otherwise; the message for the calling thread is
  *     available from fmx_last_error_string();
- *   - the library never throws and keeps no global mutable state besides the thread-local error string.
+ *   - the library never throws.  Thread safety: calls on different tables / workspaces / streams may run concurrently;
+ *     the mutable process state is (a)-(c) above plus the thread-local error string;
+ *   - device-side conditions are reported through the caller's int32 error word (fmx_fwd_out_t.error and the `error`
+ *     arguments): 1 = an index outside its field (that row is treated as absent), 2 = an in-launch hand-off of the update ran
+ *     into its spin bound (the row update of that run was SKIPPED: the table is no longer the exact result), 3 = the
+ *     forward workgroups of the fused step launch ran into theirs (the forward read rows that may be stale).  2 and 3 mean
+ *     a resident-grid assumption was violated; they have never been observed and are there so that a fault ends in a
+ *     flag, not in a hang.
  *
  * Table layout in HBM (one flat buffer for all fields; field f owns rows [field_offsets[f], field_offsets[f+1])):
  *   FMX_LAYOUT_WEIGHTS  row = [ V[0..kp) | w | pad ]                                  row_stride >= kp + 4
@@ -105,10 +120,16 @@ typedef struct fmx_fwd_out {
 int fmx_version(void);
 const char *fmx_last_error_string(void);
 
-/* Process-wide tuning switches; returns the previous value (>= 0) or a negative status for an unknown name.
+/* Process-wide tuning switches (mutable global state: see Conventions); returns the previous value (>= 0) or a negative
+ * status for an unknown name.  Every switch changes HOW the same result is computed; results are identical bits.
  *   "inline_fixup" (default 1)  1: runs that cross 64-occurrence tiles are finished inside k_fm_update by an in-launch
- *                                hand-off; 0: by a second launch (k_fm_fixup).  Both orders of summation are the same: identical bits.
- *   "sort_ahead"   (default 8)  batches sorted per side-stream launch in fmx_fm_stream (1..8). */
+ *                                hand-off; 0: by a second launch (k_fm_fixup).
+ *   "sort_ahead"   (default 8)  most batches sorted per side-stream launch in fmx_fm_stream (1..8).
+ *   "sort_chunked" (default 1)  0: one workgroup per field at every width; 1: k_sort_chunk + k_sort_merge (1,024-composite
+ *                                chunks spread over the chip, stable rank merge) from 8,192 composites per field on; 2: from 2,048 on.
+ *   "fused_step"   (default 0)  1 / 2: fmx_fm_stream launches update(s) + forward(s + 1) as ONE launch (k_fm_fused; 1: one
+ *                                agent-scope acquire per forward workgroup and plain gather loads, 2: sc1 gather loads).
+ *   "online_persistent" (default 1)  0: fmx_online_run_mlp as per-sample launches instead of one workgroup walking the stream. */
 int fmx_set_option(const char *name, int value);
 
 /* Smallest sort width for a batch: max(64, next power of two >= B); and log2 of it. */
@@ -118,9 +139,12 @@ int fmx_sorted_bbits(int B);
 /* Bytes of caller-owned device workspace a step of batch size B needs (16-byte aligned).  Layout:
  *   sorted  uint32 [16][F, Bp]       occurrence lists: (local index << bbits) | sample, padded with 0xFFFFFFFF
  *                                    (a ring of 16: fmx_fm_stream sorts up to 8 batches ahead; single steps use the first)
+ *   runs    uint32 [8][F, Bp]        Bp >= 2048 only: the chunk-sorted intermediate of the wide sort
  *   meta    int32  [F, Bp/64, 2]     per 64-entry tile: does a run come in from / go out to the neighbouring tile; with the
  *                                    in-launch hand-off word 0 is (launch sequence << 4 | states) and is polled by later tiles
  *   parts   float  [F, Bp/64, 2, 2*kp+4]  partial sums of the runs that cross a tile boundary
+ *   done    uint32 [16][32]          arrival counters of the fused step launch;  fwd2 float [B, kp] + 2 [B]: its second set of
+ *                                    forward outputs (S, dz, loss ping-pong between the caller's buffers and these)
  * The workspace must be ZERO-FILLED once before its first use (the hand-off's flag words are compared with a
  * non-zero launch sequence number; never-written words must not match one by accident).
  * Negative on a bad table. */
@@ -146,7 +170,7 @@ int fmx_fm_forward(const fmx_table_t *table, const fmx_hyper_t *hyper, const int
  *   workspace: fmx_workspace_bytes(table, B) bytes; the lists land at its start as uint32 [F, Bp],
  *   entry = (local index << bbits) | sample, padded with 0xFFFFFFFF;
  *   Bp = fmx_sorted_width(B), bbits = fmx_sorted_bbits(B); requires (max vocabulary - 1) < (0xFFFFFFFF >> bbits)
- *   and Bp <= 32768 (one workgroup sorts a field in LDS).
+ *   and Bp <= 32768 (a field's composites are merged in one workgroup's LDS).
  */
 int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, void *workspace, int32_t *error,
                          fmx_stream_t stream);

@@ -273,3 +273,49 @@ def test_exact_step_capacity_and_sub_steps():
     assert dp._sub_steps(4096) == 2 and dp._sub_steps(2048) == 1 and dp._sub_steps(16384) == 8
     dp.world = 4
     assert dp._sub_steps(4096) == 1
+
+
+def test_read_criteo_arrays_equals_read_criteo_data(golden_dir):
+    """The array reader returns the same numbers as the reference-shaped list reader (reference data_preprocess.py:29-47)."""
+    from utils import data_preprocess as dp
+    csv, emb = os.path.join(golden_dir, "handmade_train_input.csv"), os.path.join(golden_dir, "handmade_category_emb.csv")
+    a, b = dp.read_criteo_arrays(csv, emb), dp.read_criteo_data(csv, emb)
+    assert a["size"] == b["size"] and a["feature_sizes"] == b["feature_sizes"] and a["value"] is None
+    assert a["index"].dtype == np.int32 and a["index"].flags["C_CONTIGUOUS"]
+    np.testing.assert_array_equal(a["index"], np.asarray(b["index"]))
+    np.testing.assert_array_equal(a["label"], np.asarray(b["label"]))
+    assert all(v == [1] * 39 for v in b["value"])
+
+
+def test_pinned_batch_stager_on_cpu():
+    """Batches come out in order, whole, with the right dtypes; the last partial batch too; buffers are reused after
+    `depth` draws (documented); out-of-range indices raise IndexError when feature_sizes are given."""
+    import torch
+    from utils.data_preprocess import PinnedBatchStager
+    rng = np.random.default_rng(0)
+    sizes = [7, 5, 11, 3]
+    N, B = 37, 8
+    index = np.stack([rng.integers(0, s, size=N) for s in sizes], axis=1)
+    label = rng.integers(0, 2, size=N)
+    value = rng.uniform(size=(N, 4))
+    for val in (None, value):
+        for depth in (1, 2, 3):
+            st = PinnedBatchStager(index, label, B, device="cpu", value=val, depth=depth, feature_sizes=sizes)
+            assert len(st) == 5
+            seen = 0
+            for idx_d, xv_d, y_d in st:
+                n = idx_d.shape[0]
+                assert idx_d.dtype == torch.int32 and y_d.dtype == torch.float32 and (xv_d is None) == (val is None)
+                np.testing.assert_array_equal(idx_d.numpy(), index[seen:seen + n])
+                np.testing.assert_array_equal(y_d.numpy(), label[seen:seen + n].astype(np.float32))
+                if val is not None:
+                    np.testing.assert_array_equal(xv_d.numpy(), value[seen:seen + n].astype(np.float32))
+                seen += n
+            assert seen == N
+    assert len(PinnedBatchStager(index, label, B, device="cpu", drop_last=True)) == 4
+    bad = index.copy()
+    bad[3, 1] = 5
+    with pytest.raises(IndexError):
+        PinnedBatchStager(bad, label, B, device="cpu", feature_sizes=sizes)
+    with pytest.raises(ValueError):
+        PinnedBatchStager(index[:, 0], label, B, device="cpu")

@@ -163,6 +163,47 @@ def test_pickle_and_state_dict_roundtrip(name):
         m.predict([[99] * len(meta["feature_sizes"])], [[1.0] * len(meta["feature_sizes"])])
 
 
+@pytest.mark.parametrize("name", ["FMAdam", "DeepFMAdam"])
+def test_tensor_inputs_equal_nested_lists(name):
+    """The array / tensor fast path (no list conversion; CUDA int32 tensors used where they lie; Xv = None for all-ones)
+    gives the same bits as the reference's nested lists: losses, parameters after update_embedding and fit, predictions.
+    An out-of-range index in a tensor raises IndexError through the kernels' flag."""
+    from utils.data_preprocess import PinnedBatchStager
+    z, meta = load_model_fixture(name, "criteo39s")
+    Xi, Xv, Y = z["A/Xi2"], z["A/Xv2"], z["A/Y2"]
+    assert (Xv == 1).all()
+    models = []
+    for _ in range(4):
+        m = build(name, meta, meta["B2"])
+        m.load_state_dict(sub(z, "A/sd0"))
+        models.append(m)
+    a, b, c, d = models
+    la = a.update_embedding(Xi.tolist(), Xv.tolist(), Y.tolist())                       # the reference's convention
+    lb = b.update_embedding(Xi.astype(np.int64), None, Y)                               # numpy, int64 like LongTensor
+    lc = c.update_embedding(torch.from_numpy(Xi.astype(np.int32)).cuda(), torch.ones(Xi.shape, device="cuda"), torch.from_numpy(Y).cuda())
+    (idx_d, xv_d, y_d), = list(PinnedBatchStager(Xi, Y, len(Y), feature_sizes=meta["feature_sizes"]))
+    ld = d.update_embedding(idx_d, xv_d, y_d)                                            # pinned staging
+    assert float(la) == float(lb) == float(lc) == float(ld)
+    a.fit(Xi.tolist(), Xv.tolist(), Y.tolist())
+    b.fit(Xi, None, Y)
+    c.fit(torch.from_numpy(Xi).cuda(), None, torch.from_numpy(Y).cuda())
+    d.fit(idx_d, None, y_d)
+    ref = sd_np(a)
+    for m in (b, c, d):
+        got = sd_np(m)
+        for k in ref:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    np.testing.assert_array_equal(a.predict(Xi.tolist(), Xv.tolist()), c.predict(torch.from_numpy(Xi).cuda(), None))
+    bad = Xi.copy()
+    bad[2, 5] = meta["feature_sizes"][5]
+    with pytest.raises(IndexError):
+        c.update_embedding(torch.from_numpy(bad).cuda(), None, torch.from_numpy(Y).cuda())
+    c.strict_index_check = False                        # asynchronous: the flag is read when asked for
+    c.update_embedding(torch.from_numpy(bad).cuda(), None, torch.from_numpy(Y).cuda())
+    with pytest.raises(IndexError):
+        c.check_index_flag()
+
+
 def test_ftrl_pickle_resumes_bit_for_bit():
     """update_rule='ftrl': the pickle carries every coordinate's (z, n) and the bias pair, so N steps + pickle round trip
     + one more step equals the uninterrupted run bit for bit (a checkpoint of the derived weights alone would restart

@@ -28,4 +28,5 @@ print('roofline frac %.3f of 8 TB/s, %.3f of measured stream read %.0f GB/s' % (
 print('chunks', d.get('step_us_over_100_step_chunks'))
 s=d.get('secondary',{}).get('deepfm',{})
 print('deepfm', s.get('value'), s.get('ms_per_step'), s.get('error'))
+print('class_surface', d.get('class_surface'))
 "
