@@ -605,6 +605,181 @@ __global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_fm_forward_part / k_fm_forward_finish: the forward pass split over FIELD OWNERS (model-parallel multi-GPU mode)
+// ------------------------------------------------------------------------------------------------------------
+// k_fm_forward sums a sample's rows in a fixed tree: lane group `slot` (of SLOTS = 64 / LPR) adds the fields
+// slot, SLOTS + slot, 2 SLOTS + slot, ... in order, then a butterfly over the lane groups (slot ^ 1, ^ 2, ^ 4, ...).  With G
+// ranks (G a power of two dividing SLOTS) rank g owns the fields of the lane groups [g SL, (g + 1) SL), SL = SLOTS / G, holds
+// only those fields' rows, and k_fm_forward_part evaluates exactly that sub-tree for EVERY sample of the global batch:
+// G samples per wave, SL lane groups each, the butterfly levels below SL -- one record (S_part[kp], ss_part[kp], fo_part)
+// per sample.  The records of a sample meet on the rank that holds its label (an all-to-all), where k_fm_forward_finish adds
+// them in the order of the remaining butterfly levels, ((r0 + r1) + (r2 + r3)) + ..., and runs k_fm_forward's epilogue.
+// The result is bit-identical to k_fm_forward on one GPU holding every field: same additions, same order.
+struct PartArgs {
+  const float *rows;
+  const int64_t *foff;   // the owner's LOCAL table: field l of it is global field (l / SL) * SLOTS + g * SL + l % SL
+  const int32_t *idx;    // [B, F] over the owner's fields, B = global batch
+  const float *xv;       // [B, F] or null
+  float *rec;            // [B, 2 kp + 4]: S | ss | fo, 0, 0, 0
+  int32_t *error;
+  int32_t B, F, stride, sl_log2;
+};
+
+template <int LPR, int NPASS>
+__global__ __launch_bounds__(256) void k_fm_forward_part(PartArgs a) {
+  constexpr int SLOTS = WAVE / LPR;
+  constexpr int kp = LPR * 4, REC = 2 * kp + 4;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, q = lane % LPR;
+  const int SL = 1 << a.sl_log2;
+  const int slot_l = slot & (SL - 1);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int b = wave * (SLOTS >> a.sl_log2) + (slot >> a.sl_log2);
+  const bool valid = b < a.B;
+  uint32_t li[NPASS], vocab[NPASS];
+  float x[NPASS];
+  int64_t lo[NPASS];
+  bool live[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int f = p * SL + slot_l;
+    live[p] = valid && f < a.F;
+    li[p] = 0;
+    x[p] = 1.f;
+    lo[p] = 0;
+    vocab[p] = 0;
+    if (live[p]) {
+      const size_t o = (size_t)b * a.F + f;
+      li[p] = (uint32_t)a.idx[o];
+      if (a.xv) x[p] = a.xv[o];
+      lo[p] = a.foff[f];
+      vocab[p] = (uint32_t)(a.foff[f + 1] - lo[p]);
+    }
+  }
+  float4 r0[NPASS];
+  float rw[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    r0[p] = splat(0.f);
+    rw[p] = 0.f;
+    if (live[p] && li[p] < vocab[p]) {
+      const float *rp = a.rows + (size_t)(lo[p] + li[p]) * a.stride;
+      r0[p] = *reinterpret_cast<const float4 *>(rp + 4 * q);
+      if (q == 0) rw[p] = rp[kp];
+    }
+  }
+  float4 s = splat(0.f), ss = splat(0.f);
+  float fo = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    if (live[p]) {
+      if (li[p] < vocab[p]) {
+        const float4 e = x[p] * r0[p];
+        s = s + e;
+        ss = ss + e * e;
+        fo += rw[p] * x[p];
+      } else {
+        bad = true;
+      }
+    }
+  }
+  if (bad && a.error) *a.error = 1;
+  // the butterfly levels inside the owner's lane groups (wave-uniform conditions)
+#define FMX_BFLY_L(M)                              \
+  if (LPR <= M && (M / LPR) < SL) {                \
+    s = s + xor_lane_f4<M>(s, lane);               \
+    ss = ss + xor_lane_f4<M>(ss, lane);            \
+    fo += xor_lane_f<M>(fo, lane);                 \
+  }
+  FMX_BFLY_L(1) FMX_BFLY_L(2) FMX_BFLY_L(4) FMX_BFLY_L(8) FMX_BFLY_L(16) FMX_BFLY_L(32)
+#undef FMX_BFLY_L
+  if (valid && slot_l == 0) {
+    float *r = a.rec + (size_t)b * REC;
+    *reinterpret_cast<float4 *>(r + 4 * q) = s;
+    *reinterpret_cast<float4 *>(r + kp + 4 * q) = ss;
+    if (q == 0) *reinterpret_cast<float4 *>(r + 2 * kp) = float4{fo, 0.f, 0.f, 0.f};
+  }
+}
+
+struct FinishArgs {
+  const float *parts;    // [G][B, 2 kp + 4]: block r holds rank r's records of THIS rank's B samples
+  int64_t rank_stride;   // floats between the blocks
+  const float *bias;
+  const float *y;
+  fmx_fwd_out_t out;
+  fmx_hyper_t h;
+  int32_t B, loss_kind, ldS, ld1;
+  float inv_b;
+};
+
+template <int LPR, int LAYOUT, int G>
+__global__ __launch_bounds__(256) void k_fm_forward_finish(FinishArgs a) {
+  constexpr int SLOTS = WAVE / LPR;
+  constexpr int kp = LPR * 4, REC = 2 * kp + 4;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, q = lane % LPR;
+  const int b = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * SLOTS + slot;
+  const bool valid = b < a.B;
+  const float y_early = (valid && a.loss_kind != FMX_LOSS_NONE) ? a.y[b] : 0.f;
+  const float bias0 = a.bias[0];
+  const float bias1 = LAYOUT == FMX_LAYOUT_WEIGHTS ? 0.f : a.bias[1];
+  float4 s[G], ss[G];
+  float fo[G];
+#pragma unroll
+  for (int r = 0; r < G; ++r) {
+    s[r] = ss[r] = splat(0.f);
+    fo[r] = 0.f;
+    if (valid) {
+      const float *p = a.parts + (size_t)r * a.rank_stride + (size_t)b * REC;
+      s[r] = *reinterpret_cast<const float4 *>(p + 4 * q);
+      ss[r] = *reinterpret_cast<const float4 *>(p + kp + 4 * q);
+      if (q == 0) fo[r] = p[2 * kp];
+    }
+  }
+  // the butterfly levels ABOVE the owners' lane groups: rank pairs, then pairs of pairs, ...
+#pragma unroll
+  for (int st = 1; st < G; st <<= 1) {
+#pragma unroll
+    for (int r = 0; r < G; r += 2 * st) {
+      s[r] = s[r] + s[r + st];
+      ss[r] = ss[r] + ss[r + st];
+      fo[r] += fo[r + st];
+    }
+  }
+  const float4 bi = 0.5f * (s[0] * s[0] - ss[0]);
+  float sbi = (bi.x + bi.y) + (bi.z + bi.w);
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) sbi += __shfl_xor(sbi, m);
+  if (!valid) return;
+  if (a.out.S) *reinterpret_cast<float4 *>(a.out.S + (size_t)b * a.ldS + 4 * q) = s[0];
+  if (a.out.bi) *reinterpret_cast<float4 *>(a.out.bi + (size_t)b * kp + 4 * q) = bi;
+  if (q == 0) {
+    float bias;
+    if (LAYOUT == FMX_LAYOUT_WEIGHTS) bias = bias0;
+    else bias = ftrl_w(bias0, bias1, a.h);
+    const float z = fo[0] + sbi + bias;
+    if (a.out.sfirst) a.out.sfirst[b] = fo[0];
+    if (a.out.sbi) a.out.sbi[b] = sbi;
+    if (a.out.logit) a.out.logit[b] = z;
+    if (a.loss_kind != FMX_LOSS_NONE) {
+      const float y = y_early;
+      float loss, dz;
+      if (a.loss_kind == FMX_LOSS_BCE_LOGITS) {
+        loss = bcewl(z, y);
+        dz = (sigmoidf_(z) - y) * a.inv_b;
+      } else {
+        const float pp = sigmoidf_(z);
+        loss = bcewl(pp, y);
+        dz = (sigmoidf_(pp) - y) * pp * (1.f - pp) * a.inv_b;
+      }
+      if (a.out.loss) a.out.loss[(size_t)b * a.ld1] = loss;
+      if (a.out.dz) a.out.dz[(size_t)b * a.ld1] = dz;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_fm_update
 // ------------------------------------------------------------------------------------------------------------
 struct UpdArgs {
@@ -663,17 +838,25 @@ __device__ float block_sum(const float *src, int n, int ld, float *sm) {
       for (int u = 0; u < U; ++u) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
     }
     for (int i = (n4 << 2) + tid; i < n; i += nt) acc += src[i];
-  } else {  // strided sample records
-    for (int i0 = tid; i0 < n; i0 += U * nt) {
-      float v[U];
+  } else {  // strided sample records: the SAME order of additions as the dense form (groups of four elements, then the
+            // tail), so a step over gathered records and a step over dense arrays give identical bits
+    constexpr int V = 4;
+    const int n4 = n >> 2;
+    for (int i0 = tid; i0 < n4; i0 += V * nt) {
+      float4 v[V];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < V; ++u) {
         const int i = i0 + u * nt;
-        v[u] = i < n ? src[(size_t)i * ld] : 0.f;
+        v[u] = float4{0.f, 0.f, 0.f, 0.f};
+        if (i < n4) {
+          const float *p = src + (size_t)(4 * i) * ld;
+          v[u] = float4{p[0], p[ld], p[2 * (size_t)ld], p[3 * (size_t)ld]};
+        }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc += v[u];
+      for (int u = 0; u < V; ++u) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
     }
+    for (int i = (n4 << 2) + tid; i < n; i += nt) acc += src[(size_t)i * ld];
   }
   sm[tid] = acc;
   __syncthreads();
@@ -2384,6 +2567,42 @@ void launch_online_mlp(const OnlineMlpArgs &a, int layout, int rule, hipStream_t
   else launch_online_mlp_k<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM>(a, st);
 }
 
+template <int LPR>
+int launch_forward_part(const PartArgs &a, int np, hipStream_t st) {
+  const int per_wave = (WAVE / LPR) >> a.sl_log2, waves = (a.B + per_wave - 1) / per_wave;
+  const dim3 grid((waves + 3) / 4), block(256);
+  switch (np) {
+    case 1: hipLaunchKernelGGL((k_fm_forward_part<LPR, 1>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_fm_forward_part<LPR, 2>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_fm_forward_part<LPR, 3>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_fm_forward_part<LPR, 4>), grid, block, 0, st, a); break;
+    default: return fail(FMX_ERR_UNSUPPORTED, "fmx_fm_forward_partial: more than 4 fields per lane group");
+  }
+  return check_launch("k_fm_forward_part");
+}
+
+template <int LPR, int LAYOUT>
+int launch_forward_finish_g(const FinishArgs &a, int G, hipStream_t st) {
+  const int waves = (a.B + (WAVE / LPR) - 1) / (WAVE / LPR);
+  const dim3 grid((waves + 3) / 4), block(256);
+  switch (G) {
+    case 1: hipLaunchKernelGGL((k_fm_forward_finish<LPR, LAYOUT, 1>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_fm_forward_finish<LPR, LAYOUT, 2>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_fm_forward_finish<LPR, LAYOUT, 4>), grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL((k_fm_forward_finish<LPR, LAYOUT, 8>), grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL((k_fm_forward_finish<LPR, LAYOUT, 16>), grid, block, 0, st, a); break;
+    default: return fail(FMX_ERR_ARG, "fmx_fm_forward_finish: n_owners must be 1, 2, 4, 8 or 16");
+  }
+  return check_launch("k_fm_forward_finish");
+}
+
+template <int LPR>
+int launch_forward_finish(const FinishArgs &a, int layout, int G, hipStream_t st) {
+  if (G > WAVE / LPR) return fail(FMX_ERR_ARG, "fmx_fm_forward_finish: more owners than lane groups");
+  return layout == FMX_LAYOUT_WEIGHTS ? launch_forward_finish_g<LPR, FMX_LAYOUT_WEIGHTS>(a, G, st)
+                                      : launch_forward_finish_g<LPR, FMX_LAYOUT_FTRL>(a, G, st);
+}
+
 int check_forward_args(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *y, int32_t B,
                        int32_t loss_kind, const fmx_fwd_out_t *out) {
   if (int rc = check_table(table)) return rc;
@@ -2461,6 +2680,75 @@ int fmx_fm_forward(const fmx_table_t *table, const fmx_hyper_t *hyper, const int
                    fmx_stream_t stream) {
   if (int rc = check_forward_args(table, hyper, idx, y, B, loss_kind, out)) return rc;
   return forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, out, static_cast<hipStream_t>(stream));
+}
+
+int fmx_fm_forward_partial(const fmx_table_t *table, const int32_t *idx, const float *xv, int32_t B, int32_t n_owners,
+                           float *parts_out, int32_t *error, fmx_stream_t stream) {
+  if (int rc = check_table(table)) return rc;
+  if (!idx || !parts_out) return fail(FMX_ERR_ARG, "fmx_fm_forward_partial: null argument");
+  if (B < 1) return fail(FMX_ERR_ARG, "B must be >= 1");
+  if (!aligned16(parts_out)) return fail(FMX_ERR_ALIGN, "parts_out must be 16-byte aligned");
+  const int lpr = lpr_of(table->kp), slots = WAVE / lpr;
+  if (n_owners < 1 || n_owners > slots || (n_owners & (n_owners - 1))) return fail(FMX_ERR_ARG, "n_owners must be a power of two <= %d", slots);
+  const int sl = slots / n_owners;
+  int sl_log2 = 0;
+  while ((1 << sl_log2) < sl) ++sl_log2;
+  PartArgs a;
+  a.rows = table->rows;
+  a.foff = table->field_offsets;
+  a.idx = idx;
+  a.xv = xv;
+  a.rec = parts_out;
+  a.error = error;
+  a.B = B;
+  a.F = table->n_fields;
+  a.stride = table->row_stride;
+  a.sl_log2 = sl_log2;
+  const int np = (table->n_fields + sl - 1) / sl;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (lpr) {
+    case 1: return launch_forward_part<1>(a, np, st);
+    case 2: return launch_forward_part<2>(a, np, st);
+    case 4: return launch_forward_part<4>(a, np, st);
+    case 8: return launch_forward_part<8>(a, np, st);
+    default: return launch_forward_part<16>(a, np, st);
+  }
+}
+
+int fmx_fm_forward_finish(const fmx_hyper_t *hyper, const float *bias, int32_t layout, int32_t kp, const float *parts,
+                          int64_t owner_stride, int32_t n_owners, const float *y, int32_t B, int32_t loss_kind, float inv_b,
+                          const fmx_fwd_out_t *out, fmx_stream_t stream) {
+  if (!hyper || !bias || !parts || !out) return fail(FMX_ERR_ARG, "fmx_fm_forward_finish: null argument");
+  if (layout != FMX_LAYOUT_WEIGHTS && layout != FMX_LAYOUT_FTRL) return fail(FMX_ERR_ARG, "unknown layout %d", layout);
+  if (!lpr_of(kp)) return fail(FMX_ERR_SHAPE, "kp=%d must be 4/8/16/32/64", kp);
+  if (B < 1) return fail(FMX_ERR_ARG, "B must be >= 1");
+  if (loss_kind < FMX_LOSS_NONE || loss_kind > FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "unknown loss %d", loss_kind);
+  if (loss_kind != FMX_LOSS_NONE && !y) return fail(FMX_ERR_ARG, "a loss needs labels y");
+  if (!aligned16(parts) || owner_stride % 4 || (out->S && !aligned16(out->S)) || (out->bi && !aligned16(out->bi)))
+    return fail(FMX_ERR_ALIGN, "parts, S and bi must be 16-byte aligned, owner_stride a multiple of 4");
+  if (out->sample_ld != 0 && (out->sample_ld < kp || out->sample_ld % 4))
+    return fail(FMX_ERR_SHAPE, "sample_ld=%d must be 0 or a multiple of 4 that is >= kp", out->sample_ld);
+  FinishArgs a;
+  a.parts = parts;
+  a.rank_stride = owner_stride;
+  a.bias = bias;
+  a.y = y;
+  a.out = *out;
+  a.h = *hyper;
+  a.h.alpha = 1.0f / hyper->alpha;  // the kernels multiply by 1/alpha
+  a.B = B;
+  a.loss_kind = loss_kind;
+  a.ldS = out->sample_ld > 0 ? out->sample_ld : kp;
+  a.ld1 = out->sample_ld > 0 ? out->sample_ld : 1;
+  a.inv_b = inv_b;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (lpr_of(kp)) {
+    case 1: return launch_forward_finish<1>(a, layout, n_owners, st);
+    case 2: return launch_forward_finish<2>(a, layout, n_owners, st);
+    case 4: return launch_forward_finish<4>(a, layout, n_owners, st);
+    case 8: return launch_forward_finish<8>(a, layout, n_owners, st);
+    default: return launch_forward_finish<16>(a, layout, n_owners, st);
+  }
 }
 
 int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, void *workspace, int32_t *error,

@@ -163,6 +163,24 @@ int fmx_fm_forward(const fmx_table_t *table, const fmx_hyper_t *hyper, const int
                    const float *y, int32_t B, int32_t loss_kind, float inv_b, const fmx_fwd_out_t *out,
                    fmx_stream_t stream);
 
+/* ---- the forward pass split over field owners (the model-parallel multi-GPU mode; fmx/owner.py) ----
+ * fmx_fm_forward sums a sample's rows in a fixed tree: lane group `slot` of SLOTS = 64 / (kp / 4) adds the fields slot,
+ * SLOTS + slot, ... in order, then a butterfly over the lane groups.  With n_owners ranks (a power of two <= SLOTS) owner g
+ * holds the fields of the lane groups [g SL, (g + 1) SL), SL = SLOTS / n_owners, as a table of its own whose field l is global
+ * field (l / SL) * SLOTS + g * SL + l % SL, and fmx_fm_forward_partial evaluates that sub-tree for every sample of the GLOBAL
+ * batch: parts_out [B, 2 kp + 4] = per sample (S_part[kp], sum e*e part[kp], first-order part, 0, 0, 0).  The records of a sample
+ * meet on the rank that holds its label; fmx_fm_forward_finish adds them in the order of the remaining butterfly levels --
+ * owner pairs, pairs of pairs, ... -- and applies fmx_fm_forward's epilogue (bias, loss, dlogit).  The outputs are
+ * bit-identical to fmx_fm_forward on one device holding every field.
+ *   idx [B, F_local] int32 over the owner's fields, xv likewise or null; error as in fmx_fwd_out_t
+ *   parts [n_owners][B, 2 kp + 4], owner r's block owner_stride floats after owner r-1's; bias [1] or [2] as in fmx_table_t
+ * Replaces: the same reference sites as fmx_fm_forward (deepfm_adam.py:46-77, fm_adam.py:35-53, :61,66 / :76,80). */
+int fmx_fm_forward_partial(const fmx_table_t *table, const int32_t *idx, const float *xv, int32_t B, int32_t n_owners,
+                           float *parts_out, int32_t *error, fmx_stream_t stream);
+int fmx_fm_forward_finish(const fmx_hyper_t *hyper, const float *bias, int32_t layout, int32_t kp, const float *parts,
+                          int64_t owner_stride, int32_t n_owners, const float *y, int32_t B, int32_t loss_kind, float inv_b,
+                          const fmx_fwd_out_t *out, fmx_stream_t stream);
+
 /* Occurrence lists: for every field, the batch's (local index, sample) pairs sorted by index then sample.
  * Replaces: the duplicate-row summation embedding_dense_backward performs inside loss.backward()
  * (reference fm_adam.py:67,81) -- sorting is what makes "reduce per unique row, then

@@ -170,8 +170,8 @@ def test_tensor_inputs_equal_nested_lists(name):
     An out-of-range index in a tensor raises IndexError through the kernels' flag."""
     from utils.data_preprocess import PinnedBatchStager
     z, meta = load_model_fixture(name, "criteo39s")
-    Xi, Xv, Y = z["A/Xi2"], z["A/Xv2"], z["A/Y2"]
-    assert (Xv == 1).all()
+    Xi, Y = z["A/Xi2"], z["A/Y2"]
+    Xv = np.ones(Xi.shape, dtype=np.float32)              # the Criteo case: every value is 1 (None on the array path)
     models = []
     for _ in range(4):
         m = build(name, meta, meta["B2"])
