@@ -287,6 +287,9 @@ def main():
     ap.add_argument("--loop-only", action="store_true", help="only the timed online loop (no measuring pass, no spread pass): "
                                                              "what tools/profile_round.sh traces for the in-loop kernel durations")
     ap.add_argument("--row-stride", type=int, default=0)
+    ap.add_argument("--mp-mode", default="owner", choices=["owner", "replicated"],
+                    help="N > 1: 'owner' = field-owner mode (fmx.owner: table and update work shard over the ranks), "
+                         "'replicated' = every rank keeps the whole table and repeats the global update (fmx.DataParallelFM)")
     ap.add_argument("--model", default="FMAdam", choices=sorted(PUBLISHED_ONLINE), help="--workload online: the class `value` reports")
     ap.add_argument("--workload", default="fm", choices=["fm", "deepfm", "online"],
                     help="fm: the headline metric (BASELINE configs[1]+[2]); deepfm: configs[3], bi-interaction + 3x256 relu "
@@ -327,17 +330,27 @@ def main():
             print(json.dumps(out))
         return
     RULE = args.rule
-    table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="ftrl" if RULE == "ftrl" else "weights", device=dev,
-                          row_stride=args.row_stride if args.row_stride else None, ftrl=HYPER)
-    g = torch.Generator(device=dev).manual_seed(SEED)
-    w0 = torch.randn((table.n_rows, K_EMB), generator=g, device=dev) * 0.01
-    table.rows[:, :K_EMB] = w0
-    if RULE == "ftrl":          # n = 0 and the z that reproduces V (first-order weights and bias start at 0)
-        zo = table.z_offset
-        table.rows[:, zo:zo + K_EMB] = fmx.table.ftrl_z_for_weight_torch(w0, table.ftrl)
-    del w0
     hyper = fmx.Hyper(**HYPER)
-    eng = fmx.FMEngine(table, max_batch=BATCH * world)
+    owner_mode = world > 1 and args.mp_mode == "owner"
+
+    def init_rows(t, seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        w0 = torch.randn((t.n_rows, K_EMB), generator=g, device=dev) * 0.01
+        t.rows[:, :K_EMB] = w0
+        if RULE == "ftrl":      # n = 0 and the z that reproduces V (first-order weights and bias start at 0)
+            zo = t.z_offset
+            t.rows[:, zo:zo + K_EMB] = fmx.table.ftrl_z_for_weight_torch(w0, t.ftrl)
+    if owner_mode:
+        # the field-owner mode (fmx.owner): every rank holds only the rows of its fields
+        from fmx.owner import FieldOwnerFM, HipOwnerBackend
+        obe = HipOwnerBackend(CRITEO_SIZES, K_EMB, hyper, RULE, "logits", rank, world, ftrl=HYPER, device=dev, max_local_batch=BATCH)
+        init_rows(obe.table, SEED + rank)
+        table, eng = obe.table, obe.e
+    else:
+        table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="ftrl" if RULE == "ftrl" else "weights", device=dev,
+                              row_stride=args.row_stride if args.row_stride else None, ftrl=HYPER)
+        init_rows(table, SEED)
+        eng = fmx.FMEngine(table, max_batch=BATCH * world)
     idx_np, y_np = synth_pool(N_POOL, BATCH, CRITEO_SIZES, SEED + 1000 * rank, zipf=args.zipf)
     idx_pool = torch.from_numpy(idx_np).to(dev)
     y_pool = torch.from_numpy(y_np).to(dev)
@@ -398,9 +411,24 @@ def main():
     else:
         # ---- N GPUs: exact data parallelism (fmx.DataParallelFM): forward on the local slice, all-gather of the
         #      low-rank factors (idx, S, dlogit) over RCCL, identical row-reduced update of the replicas ----
-        dp = fmx.DataParallelFM(fmx.HipBackend(eng, hyper, RULE, "logits"))
+        dp = None if owner_mode else fmx.DataParallelFM(fmx.HipBackend(eng, hyper, RULE, "logits"))
+        fo = FieldOwnerFM(obe) if owner_mode else None
+
+        def run_owner(n, first=0):
+            # the index all-gather, the column pick and the sort of the owned fields run two steps ahead on the prefetch stream
+            out, tokens = None, {}
+            for d in range(min(2, n)):
+                tokens[d] = fo.prefetch(idx_pool[(first + d) % N_POOL])
+            for s in range(n):
+                j = (first + s) % N_POOL
+                out = fo.step(idx_pool[j], y_pool[j], tokens.pop(s, None))
+                if s + 2 < n:
+                    tokens[s + 2] = fo.prefetch(idx_pool[(first + s + 2) % N_POOL])
+            return out
 
         def run(n, first=0):
+            if owner_mode:
+                return run_owner(n, first)
             # the index all-gather and the global sort of later steps run ahead on two prefetch streams: two steps ahead when
             # a step is one exact update (two global sorts in flight: one alone is as long as the step or longer), one
             # step (= all its sub-steps) ahead when the global batch is split
@@ -433,7 +461,14 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    parallelism = f"dp{world}: replicated table, all-gather of (idx, S, dlogit), identical update on every replica (exact)"
+    parallelism = (f"field owners x{world}: every rank holds and updates the rows of its fields only (table and update work "
+                   "sharded); per step an all-gather of idx (ahead of time), an all-to-all of per-sample partial sums (144 B) and "
+                   "an all-gather of (S, dlogit, loss) (80 B); bit-identical to one GPU on the same global batch"
+                   if owner_mode else
+                   f"dp{world}: replicated table, all-gather of (idx, S, dlogit), identical update on every replica (exact)")
+    if world > 1:
+        sub = (fo if owner_mode else dp)._sub_steps(BATCH)
+        parallelism += f"; {sub} exact update(s) per step (global batch {BATCH * world})"
 
     if stream_gbps is None:
         stream_gbps = stream_read_probe(fmx, torch, dev)

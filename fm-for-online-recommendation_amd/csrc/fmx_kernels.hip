@@ -134,10 +134,13 @@ struct SortArgs {
   int32_t n_pool, pool_first, n_batches;
   int64_t pool_stride, sorted_stride;  // in elements
   const int32_t *idx;
-  const int64_t *foff;
+  const int64_t *foff;   // the fields' row offsets (range check of an index against its field)
+  const int64_t *soff;   // the SORT fields' row offsets: a refinement of foff (fmx_table_t.sort_offsets), or foff itself
+  const int32_t *cols;   // the field (idx column) every sort field is a piece of, or null (sort field == field)
   uint32_t *sorted;
   int32_t *error;
-  int32_t B, F, Bp, bbits;
+  int32_t B, F, Bp, bbits;  // F: number of SORT fields
+  int32_t Fi;               // number of fields = columns of idx
 };
 
 // lane ^ M exchanges without the LDS crossbar (ds_bpermute made the sort LDS-pipe bound): DPP for M = 1, 2, 4, 8,
@@ -216,21 +219,27 @@ __device__ __forceinline__ void bitonic_local(uint32_t (&v)[E], int tid, int k, 
 
 // composites of samples i0 .. i0 + E - 1 of field f: every index load is issued before the first is used (a branch per
 // element -- range check, error flag -- made the compiler wait for each load in turn: E dependent HBM round trips)
+// Sort field f is rows [soff[f], soff[f + 1]) of field col: an index outside that piece belongs to another piece of the
+// field (padding here, no error); an index outside the FIELD raises the flag.
 template <int E>
-__device__ __forceinline__ void load_composites(const SortArgs &a, int f, int i0, uint32_t vocab, uint32_t (&v)[E]) {
+__device__ __forceinline__ void load_composites(const SortArgs &a, int f, int i0, uint32_t (&v)[E]) {
+  const int col = a.cols ? a.cols[f] : f;
+  const int64_t f_lo = a.foff[col];
+  const uint32_t field_rows = (uint32_t)(a.foff[col + 1] - f_lo);
+  const uint32_t base = (uint32_t)(a.soff[f] - f_lo), piece_rows = (uint32_t)(a.soff[f + 1] - a.soff[f]);
   uint32_t li[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const int i = i0 + r;
-    li[r] = (uint32_t)a.idx[(size_t)(i < a.B ? i : a.B - 1) * a.F + f];
+    li[r] = (uint32_t)a.idx[(size_t)(i < a.B ? i : a.B - 1) * a.Fi + col];
   }
   bool bad = false;
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const int i = i0 + r;
-    const bool in_range = li[r] < vocab;
-    v[r] = (i < a.B && in_range) ? ((li[r] << a.bbits) | (uint32_t)i) : SENT;
-    bad = bad || (i < a.B && !in_range);
+    const uint32_t lp = li[r] - base;  // wraps to a huge value below the piece
+    v[r] = (i < a.B && lp < piece_rows) ? ((lp << a.bbits) | (uint32_t)i) : SENT;
+    bad = bad || (i < a.B && li[r] >= field_rows);
   }
   if (bad && a.error) *a.error = 1;
 }
@@ -242,9 +251,8 @@ __device__ __forceinline__ void load_composites(const SortArgs &a, int f, int i0
 template <int E>
 __device__ __forceinline__ void sort_field(const SortArgs &a, int f, uint32_t *sm) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  const uint32_t vocab = (uint32_t)(a.foff[f + 1] - a.foff[f]);
   uint32_t v[E];
-  load_composites<E>(a, f, tid * E, vocab, v);
+  load_composites<E>(a, f, tid * E, v);
   const int wave_span = 64 * E;  // elements held by one wave
   uint32_t *dst = a.sorted + (size_t)f * a.Bp;
   const int half = a.Bp >> 1;
@@ -331,12 +339,11 @@ __global__ __launch_bounds__(SORT_CHUNK_THREADS) void k_sort_chunk(ChunkArgs a) 
   const int32_t *idx = a.s.idx + (size_t)((a.s.pool_first + j) % a.s.n_pool) * a.s.pool_stride;
   uint32_t *dst = a.runs + (size_t)j * a.runs_stride + (size_t)f * a.s.Bp + (size_t)c * SORT_CHUNK;
   const int tid = threadIdx.x;
-  const uint32_t vocab = (uint32_t)(a.s.foff[f + 1] - a.s.foff[f]);
   uint32_t v[E];
   {
     SortArgs sa = a.s;
     sa.idx = idx;
-    load_composites<E>(sa, f, c * SORT_CHUNK + tid * E, vocab, v);
+    load_composites<E>(sa, f, c * SORT_CHUNK + tid * E, v);
   }
   constexpr int wave_span = 64 * E;
   for (int k = 2; k <= SORT_CHUNK; k <<= 1) {
@@ -800,6 +807,8 @@ struct UpdArgs {
   fmx_hyper_t h;
   int32_t B, F, Bp, bbits, kp, stride, zoff;
   int32_t ldS, ld1;  // floats between consecutive samples in S and in dz_first / dz_bi / loss_b (kp and 1 when dense)
+  const int32_t *cols;  // sort field -> field (column of xv), or null; Fx: columns of xv
+  int32_t Fx;
   uint32_t seq;      // INL: launch sequence number tagging the tile meta words of this launch
   int32_t *error;    // INL: set to 2 if a hand-off wait ran into its bound
   float inv_b;
@@ -1079,7 +1088,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
     if (val[j]) {
       const uint32_t b = c[j] & bmask;
       const float4 S4 = *reinterpret_cast<const float4 *>(a.S + (size_t)b * a.ldS + 4 * q);
-      const float x = a.xv ? a.xv[(size_t)b * a.F + f] : 1.f;
+      const float x = a.xv ? a.xv[(size_t)b * a.Fx + (a.cols ? a.cols[f] : f)] : 1.f;
       const float dzf = a.dz_first[(size_t)b * a.ld1];
       const float dzb = a.dz_bi == a.dz_first ? dzf : (a.dz_bi ? a.dz_bi[(size_t)b * a.ld1] : 0.f);
       cw[j] = x * dzf;
@@ -2054,6 +2063,9 @@ int check_table(const fmx_table_t *t) {
     return fail(FMX_ERR_SHAPE, "row_stride=%d must be a multiple of 4 and >= %d", t->row_stride, need);
   if (!aligned16(t->rows)) return fail(FMX_ERR_ALIGN, "table rows must be 16-byte aligned");
   if (t->max_field_rows < 1 || t->max_field_rows > t->n_rows) return fail(FMX_ERR_SHAPE, "max_field_rows out of range");
+  if (t->n_sort_fields < 0 || (t->n_sort_fields > 0 && (t->n_sort_fields < t->n_fields || !t->sort_offsets || !t->sort_cols ||
+                                                        t->max_sort_field_rows < 1 || t->max_sort_field_rows > t->max_field_rows)))
+    return fail(FMX_ERR_SHAPE, "sort fields: n_sort_fields >= n_fields with sort_offsets, sort_cols and max_sort_field_rows, or 0");
   return FMX_OK;
 }
 
@@ -2068,15 +2080,21 @@ int check_rule(const fmx_table_t *t, int rule) {
   return FMX_OK;
 }
 
+// the SORT fields of a table: its fields, or the finer partition fmx_table_t.sort_offsets describes
+inline int n_sort_fields(const fmx_table_t *t) { return t->n_sort_fields > 0 ? t->n_sort_fields : t->n_fields; }
+inline const int64_t *sort_offsets(const fmx_table_t *t) { return t->n_sort_fields > 0 ? t->sort_offsets : t->field_offsets; }
+inline const int32_t *sort_cols(const fmx_table_t *t) { return t->n_sort_fields > 0 ? t->sort_cols : nullptr; }
+inline int64_t max_sort_rows(const fmx_table_t *t) { return t->n_sort_fields > 0 ? t->max_sort_field_rows : t->max_field_rows; }
+
 int check_sort_geometry(const fmx_table_t *t, int B) {
   if (B < 1) return fail(FMX_ERR_ARG, "B must be >= 1");
   const int Bp = fmx_sorted_width(B);
   if (Bp > MAX_SORT_WIDTH)
     return fail(FMX_ERR_UNSUPPORTED, "batch %d exceeds the LDS sort width %d", B, MAX_SORT_WIDTH);
   const int bbits = fmx_sorted_bbits(B);
-  if ((uint64_t)(t->max_field_rows - 1) >= (uint64_t)(SENT >> bbits))
-    return fail(FMX_ERR_UNSUPPORTED, "largest field (%lld rows) and batch %d do not fit a 32-bit (index, sample) composite",
-                (long long)t->max_field_rows, B);
+  if ((uint64_t)(max_sort_rows(t) - 1) >= (uint64_t)(SENT >> bbits))
+    return fail(FMX_ERR_UNSUPPORTED, "largest sort field (%lld rows) and batch %d do not fit a 32-bit (index, sample) composite: "
+                "split the large fields (fmx_table_t.sort_offsets)", (long long)max_sort_rows(t), B);
   return FMX_OK;
 }
 
@@ -2142,7 +2160,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 #include "fmx_mlp_gemm.inc"
 
 Workspace carve(const fmx_table_t *t, int B, void *base) {
-  const size_t F = (size_t)t->n_fields, Bp = (size_t)fmx_sorted_width(B), tiles = Bp >> 6;
+  const size_t F = (size_t)n_sort_fields(t), Bp = (size_t)fmx_sorted_width(B), tiles = Bp >> 6;
   const size_t rec = 2 * (size_t)t->kp + 4;
   const size_t o_sorted1 = align_up(F * Bp * 4, 256);
   const size_t o_runs = 2 * SORT_AHEAD_MAX * o_sorted1;
@@ -2314,7 +2332,7 @@ bool fused_eligible(const fmx_table_t *table, int32_t B, int rule, hipStream_t s
   if (table->kp != 16 || table->n_fields > 64 || B < OVERLAP_MIN_BATCH) return false;
   if ((uint64_t)table->n_rows * (uint64_t)table->row_stride * 4ull >= (1ull << 32)) return false;
   const int np = (table->n_fields + 15) / 16;
-  const int tiles = table->n_fields * (fmx_sorted_width(B) >> 6);
+  const int tiles = n_sort_fields(table) * (fmx_sorted_width(B) >> 6);
   const int wpb = tune().fused_wpb;
   const int n_blocks = 1 + (tiles + wpb - 1) / wpb + (B + wpb * FUSE_SPW - 1) / (wpb * FUSE_SPW);
   int dev = 0, cus = 0, per_cu = 0;
@@ -2399,10 +2417,13 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
   a.sorted_stride = mb ? mb->sorted_stride : 0;
   a.idx = idx;
   a.foff = table->field_offsets;
+  a.soff = sort_offsets(table);
+  a.cols = sort_cols(table);
   a.sorted = sorted;
   a.error = error;
   a.B = B;
-  a.F = table->n_fields;
+  a.F = n_sort_fields(table);
+  a.Fi = table->n_fields;
   a.Bp = fmx_sorted_width(B);
   a.bbits = fmx_sorted_bbits(B);
   if (a.Bp >= (tune().sort_chunked > 1 ? 2 * SORT_CHUNK : SORT_CHUNKED_MIN_WIDTH) && tune().sort_chunked && runs) {
@@ -2484,7 +2505,9 @@ UpdArgs fill_upd(const fmx_table_t *table, const fmx_hyper_t *hyper, const Works
   if (a.seq == 0) a.seq = launch_seq.fetch_add(1) & 0x0FFFFFFFu;  // 0 is what a zeroed workspace holds
   a.error = err_flag;
   a.rows = table->rows;
-  a.foff = table->field_offsets;
+  a.foff = sort_offsets(table);  // the update walks the SORT fields' lists; a sort field's rows start at its own offset
+  a.cols = sort_cols(table);
+  a.Fx = table->n_fields;
   a.bias = table->bias;
   a.sorted = sorted;
   a.parts = w.parts;
@@ -2499,7 +2522,7 @@ UpdArgs fill_upd(const fmx_table_t *table, const fmx_hyper_t *hyper, const Works
   a.step_counter = step_counter;
   a.h = *hyper;
   a.B = B;
-  a.F = table->n_fields;
+  a.F = n_sort_fields(table);
   a.Bp = fmx_sorted_width(B);
   a.bbits = fmx_sorted_bbits(B);
   a.kp = table->kp;

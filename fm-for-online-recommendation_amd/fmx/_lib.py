@@ -33,7 +33,9 @@ class FmxError(RuntimeError):
 class Table(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("field_offsets", C.c_void_p), ("bias", C.c_void_p), ("n_rows", C.c_int64),
                 ("n_fields", C.c_int32), ("k", C.c_int32), ("kp", C.c_int32), ("row_stride", C.c_int32),
-                ("layout", C.c_int32), ("z_offset", C.c_int32), ("max_field_rows", C.c_int64)]
+                ("layout", C.c_int32), ("z_offset", C.c_int32), ("max_field_rows", C.c_int64),
+                ("sort_offsets", C.c_void_p), ("sort_cols", C.c_void_p), ("n_sort_fields", C.c_int32), ("reserved", C.c_int32),
+                ("max_sort_field_rows", C.c_int64)]
 
 
 class Hyper(C.Structure):

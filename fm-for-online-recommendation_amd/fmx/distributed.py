@@ -17,13 +17,9 @@ import torch.distributed as dist
 
 
 def max_step_batch(max_field_rows):
-    """Largest batch one exact step can take: the occurrence sort packs (local index, sample) into 32 bits and sorts a
-    field inside one workgroup's LDS (include/fmx.h), so  (max_field_rows - 1) < (0xFFFFFFFF >> log2(batch))  and
-    batch <= 32768."""
-    bbits = 15
-    while bbits > 6 and (max_field_rows - 1) >= (0xFFFFFFFF >> bbits):
-        bbits -= 1
-    return 1 << bbits
+    """Largest batch one exact step can take: 32,768 (a field's occurrence list is merged inside one workgroup's LDS;
+    include/fmx.h).  The 32-bit (index, sample) composite no longer bounds it: large fields are cut into sort pieces."""
+    return 32768       # fields too large for a 32-bit (index, sample) composite are cut into sort pieces (FlatTable.ensure_sort_split)
 
 
 class HipBackend:

@@ -61,13 +61,15 @@ class FMEngine:
     def _alloc(self, B):
         B = int(B)
         t, dev = self.table, self.device
+        t.ensure_sort_split(B)                       # large fields are cut into sort pieces when (index, sample) would not fit 32 bits
         Bp = self.lib.fmx_sorted_width(B)
         f32 = dict(dtype=torch.float32, device=dev)
         nbytes = int(self.lib.fmx_workspace_bytes(t.c_struct(), B))
         if nbytes < 0:
             _lib.check(nbytes)
         self.workspace = torch.zeros(nbytes // 4, dtype=torch.int32, device=dev)
-        self.sorted = self.workspace[:t.n_fields * Bp].view(t.n_fields, Bp)     # the occurrence lists (uint32 bits)
+        nsf = t.n_fields if t._sort_split is None else t._sort_split[1].numel()
+        self.sorted = self.workspace[:nsf * Bp].view(nsf, Bp)     # the occurrence lists (uint32 bits), one per sort field
         self.S = torch.empty((B, t.kp), **f32)
         self.bi = torch.empty((B, t.kp), **f32)
         self.first = torch.empty((B, t.n_fields), **f32)

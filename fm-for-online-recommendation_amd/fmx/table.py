@@ -80,6 +80,8 @@ class FlatTable:
         self.offsets = torch.from_numpy(offs).to(self.device)
         self.bias = torch.zeros(1 if layout == "weights" else 2, dtype=torch.float32, device=self.device)
         self._cstruct = None
+        self._sort_split = None
+        self.sort_cap_override = None
 
     # ---- C view ----
     def c_struct(self):
@@ -94,8 +96,39 @@ class FlatTable:
             t.layout = _lib.LAYOUT_WEIGHTS if self.layout == "weights" else _lib.LAYOUT_FTRL
             t.z_offset = self.z_offset
             t.max_field_rows = max(self.feature_sizes)
+            if self._sort_split is not None:
+                so, sc, mx = self._sort_split
+                t.sort_offsets, t.sort_cols, t.n_sort_fields, t.max_sort_field_rows = so.data_ptr(), sc.data_ptr(), sc.numel(), mx
             self._cstruct = t
         return C.byref(self._cstruct)
+
+    # ---- sort fields: pieces of the large fields, so that (index, sample) fits 32 bits at large batches ----
+    def ensure_sort_split(self, B):
+        """An exact step over B samples packs (index within the sort field, sample) into 32 bits (include/fmx.h, "SORT
+        FIELDS"): fields with more rows than that leaves room for are cut into equal consecutive pieces.  Called by FMEngine
+        whenever its largest batch grows; a no-op for the Criteo vocabulary up to 16,384 samples."""
+        bbits = max(6, int(np.ceil(np.log2(max(int(B), 1)))))
+        cap = 0xFFFFFFFF >> bbits                              # rows a sort field may have
+        if self.sort_cap_override:                             # tests: force a finer split (identical results, more sort fields)
+            cap = min(cap, int(self.sort_cap_override))
+        if max(self.feature_sizes) <= cap:
+            if self._sort_split is not None:
+                self._sort_split, self._cstruct = None, None
+            return
+        offs, cols, mx = [0], [], 0
+        for f, size in enumerate(self.feature_sizes):
+            n = (size + cap - 1) // cap
+            base, lo = size // n, int(self.offsets_host[f])
+            for j in range(n):
+                rows = base + (1 if j < size % n else 0)
+                lo += rows
+                offs.append(lo)
+                cols.append(f)
+                mx = max(mx, rows)
+        so = torch.tensor(offs, dtype=torch.int64, device=self.device)
+        sc = torch.tensor(cols, dtype=torch.int32, device=self.device)
+        if self._sort_split is None or self._sort_split[1].numel() != sc.numel() or self._sort_split[2] != mx:
+            self._sort_split, self._cstruct = (so, sc, mx), None
 
     # ---- strided views into the flat buffer (both layouts keep [ V | w ] at the head of the row) ----
     @property

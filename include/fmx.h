@@ -93,6 +93,17 @@ typedef struct fmx_table {
   int32_t layout;     /* enum fmx_layout */
   int32_t z_offset;   /* FTRL: float offset of zV inside the row (multiple of 4, >= kp + 4); WEIGHTS: ignored */
   int64_t max_field_rows; /* largest per-field vocabulary (host copy; bounds the sort's composite keys) */
+  /* SORT FIELDS (optional; n_sort_fields = 0: the fields themselves).  The occurrence lists and the update work per "sort
+   * field".  An occurrence list packs (index, sample) into 32 bits, so a field of 176,373 rows (18 bits) leaves 14 bits for
+   * the sample: 16,384 samples per exact step.  A field may therefore be cut into consecutive PIECES of at most
+   * max_sort_field_rows rows, each sorted and updated as a field of its own (a sample appears in the list of the one piece
+   * its index falls into): sort_offsets [n_sort_fields + 1] (host-built, device-resident) refines field_offsets,
+   * sort_cols [n_sort_fields] names the field every piece belongs to.  The forward pass is unaffected. */
+  const int64_t *sort_offsets;
+  const int32_t *sort_cols;
+  int32_t n_sort_fields;
+  int32_t reserved;
+  int64_t max_sort_field_rows;
 } fmx_table_t;
 
 typedef struct fmx_hyper {
@@ -137,6 +148,7 @@ int fmx_sorted_width(int B);
 int fmx_sorted_bbits(int B);
 
 /* Bytes of caller-owned device workspace a step of batch size B needs (16-byte aligned).  Layout:
+ *   (F below: the number of SORT fields of the table, = n_fields unless large fields are split)
  *   sorted  uint32 [16][F, Bp]       occurrence lists: (local index << bbits) | sample, padded with 0xFFFFFFFF
  *                                    (a ring of 16: fmx_fm_stream sorts up to 8 batches ahead; single steps use the first)
  *   runs    uint32 [8][F, Bp]        Bp >= 2048 only: the chunk-sorted intermediate of the wide sort
@@ -187,7 +199,7 @@ int fmx_fm_forward_finish(const fmx_hyper_t *hyper, const float *bias, int32_t l
  * update once" deterministic.
  *   workspace: fmx_workspace_bytes(table, B) bytes; the lists land at its start as uint32 [F, Bp],
  *   entry = (local index << bbits) | sample, padded with 0xFFFFFFFF;
- *   Bp = fmx_sorted_width(B), bbits = fmx_sorted_bbits(B); requires (max vocabulary - 1) < (0xFFFFFFFF >> bbits)
+ *   Bp = fmx_sorted_width(B), bbits = fmx_sorted_bbits(B); requires (largest sort field - 1) < (0xFFFFFFFF >> bbits)
  *   and Bp <= 32768 (a field's composites are merged in one workgroup's LDS).
  */
 int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, void *workspace, int32_t *error,

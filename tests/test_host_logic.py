@@ -252,17 +252,23 @@ def test_rrf_online_vs_reference(task, golden_dir, capsys):
 
 
 def test_exact_step_capacity_and_sub_steps():
-    """The largest batch one exact step can take (32-bit (index, sample) composites sorted inside one workgroup's LDS) and
-    how DataParallelFM splits a global batch that exceeds it."""
+    """The largest batch one exact step can take is the LDS merge width, whatever the vocabulary: a field whose indices
+    would not fit a 32-bit (index, sample) composite is cut into sort pieces (FlatTable.ensure_sort_split).  How the
+    multi-GPU wrappers split a global batch that exceeds a backend's cap."""
     import fmx
     from fmx.distributed import DataParallelFM, max_step_batch
-    assert max_step_batch(3) == 32768                       # LDS sort width
-    assert max_step_batch((1 << 17) - 1) == 32768           # 17 index bits + 15 sample bits, 0xFFFFFFFF stays free
-    assert max_step_batch(1 << 17) == 16384                 # index 2^17 - 1 with sample 2^15 - 1 would be 0xFFFFFFFF
-    assert max_step_batch((1 << 18) - 1) == 16384           # 18 index bits (the Criteo list's largest field)
-    assert max_step_batch(1 << 18) == 8192
-    assert max_step_batch((1 << 20) - 1) == 4096            # 20 index bits + 12 sample bits
-    assert max_step_batch(1 << 24) == 128
+    assert max_step_batch(3) == 32768 and max_step_batch(1 << 24) == 32768
+    # the split: 18-bit fields stay whole up to 16,384 samples and fall into two pieces at 32,768
+    t = fmx.FlatTable([3, 176373, 10, 131071, 131072], 4, device="cpu")
+    t.ensure_sort_split(16384)
+    assert t._sort_split is None
+    t.ensure_sort_split(32768)
+    so, sc, mx = t._sort_split
+    assert sc.tolist() == [0, 1, 1, 2, 3, 4, 4] and mx == 131071              # 176373 -> 88187 + 88186, 131071 whole, 131072 -> 2 x 65536
+    assert so.tolist() == [0, 3, 3 + 88187, 3 + 176373, 176386, 176386 + 131071, 176386 + 131071 + 65536, 176386 + 131071 + 131072]
+    assert mx <= (0xFFFFFFFF >> 15)
+    t.ensure_sort_split(4096)
+    assert t._sort_split is None
 
     class Backend:
         max_global_batch = 16384

@@ -446,6 +446,62 @@ def test_fused_step_launch_equals_separate_launches(fmx, rule, zipf, n_steps):
     assert np.isfinite(res[0][2]).all() and (res[0][2] > 0).all()
 
 
+@pytest.mark.parametrize("rule,real_x", [("ftrl", False), ("sgd", True)])
+def test_split_sort_fields_equal_whole_fields(fmx, rule, real_x):
+    """Large fields cut into sort pieces (fmx_table_t.sort_offsets; needed when (index, sample) would not fit 32 bits) are
+    sorted and updated piece by piece: the same rows get the same sums.  A run of equal rows then sits at another offset of
+    its list, so the 64-occurrence tiles group its terms differently: equal within fp32 rounding, not bit for bit (the
+    float64 check of the split is test_one_exact_step_of_32768_samples_with_an_18_bit_field).  Forced here at a small batch
+    (pieces of at most 700 rows), including real-valued x (the piece -> field column map)."""
+    sizes, k, B = [3, 5000, 17, 50000, 2, 901], 16, 1500
+    pr = make_problem(sizes, k, B, seed=33, real_x=real_x)
+    hyp = fmx.Hyper(**HYP)
+    res = []
+    for cap in (None, 700):
+        t = ftrl_table(fmx, sizes, k, ftrl_state(pr, HYP)) if rule == "ftrl" else weights_table(fmx, sizes, k, pr)
+        t.sort_cap_override = cap
+        eng = fmx.FMEngine(t, max_batch=B)
+        assert (t._sort_split is None) == (cap is None)
+        if cap is not None:
+            assert t._sort_split[1].numel() == 1 + 8 + 1 + 72 + 1 + 2 and t._sort_split[2] <= 700
+        idx_d, xv_d, y_d = eng.to_device(pr["idx"], pr["x"], pr["y"])
+        losses = []
+        for _ in range(3):
+            eng.step(hyp, rule, "logits", idx_d, xv_d, y_d)
+            losses.append(float(eng.loss_out.item()))
+        eng.check_error_flag()
+        res.append((t.rows.cpu().numpy(), t.bias.cpu().numpy(), losses))
+    # three lr-sized steps on O(0.3) weights / O(10) z: 1e-5 of the values, and the untouched rows identical
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-6)
+    assert (res[0][0] == res[1][0]).mean() > 0.9
+
+
+def test_one_exact_step_of_32768_samples_with_an_18_bit_field(fmx):
+    """8 GPUs x 4,096 samples is one exact step of 32,768: 15 sample bits leave 17 index bits, the Criteo list's largest
+    fields need 18 -- they are split into two sort pieces automatically.  Against the float64 step."""
+    sizes, k, B = [3, 176373, 19, 129683, 44549], 16, 32768
+    pr = make_problem(sizes, k, B, seed=8)
+    st = ftrl_state(pr, HYP)
+    st0 = {kk: np.array(v, copy=True) for kk, v in st.items()}
+    t = ftrl_table(fmx, sizes, k, st)
+    eng = fmx.FMEngine(t, max_batch=B)
+    assert t._sort_split is not None and t._sort_split[1].tolist() == [0, 1, 1, 2, 3, 4]
+    idx_d, _, y_d = eng.to_device(pr["idx"], None, pr["y"])
+    eng.step(fmx.Hyper(**HYP), "ftrl", "logits", idx_d, None, y_d)
+    torch.cuda.synchronize()
+    eng.check_error_flag()
+    h = dict(alpha=HYP["alpha"], beta=HYP["beta"], l1=HYP["l1"], l2=HYP["l2"])
+    ref = orc.flat_fm_step_f64(st0, pr["rows"], np.ones((B, len(sizes)), np.float32), pr["y"], "logits", "ftrl", h)
+    assert_within_f64(float(eng.loss_out.item()), ref["loss"], ref["floor"]["loss"], "loss")
+    zV, nV, zw, nw = [a.numpy() for a in t.export_ftrl_state()]
+    assert_ftrl_step_within_f64(dict(zV=zV, nV=nV, zw=zw, nw=nw, zb=t.bias[0].item(), nb=t.bias[1].item()), ref)
+    srt = eng.sorted.cpu().numpy().view(np.uint32)
+    assert srt.shape[0] == 6 and (np.diff(srt.astype(np.int64), axis=1) >= 0).all()
+    assert ((srt != 0xFFFFFFFF).sum(axis=1)[[1, 2]].sum()) == B          # every sample is in exactly one piece of field 1
+
+
 def test_abi_rejects_bad_arguments(fmx):
     pr = make_problem(MIXED_SIZES, 4, 8, seed=1)
     t = weights_table(fmx, MIXED_SIZES, 4, pr)
@@ -455,8 +511,12 @@ def test_abi_rejects_bad_arguments(fmx):
         eng.step(fmx.Hyper(**HYP), "ftrl", "logits", idx_d, None, y_d)     # FTRL rule on a weights-layout table
     assert ei.value.code == fmx._lib.ERR_ARG
     big = fmx.FlatTable([1 << 22, 5], 4)                                      # 22 index bits + 12 sample bits > 32
-    e2 = fmx.FMEngine(big, max_batch=4096)
+    e2 = fmx.FMEngine(big, max_batch=4096)                                     # ... so the engine cuts the field into sort pieces
+    assert big._sort_split is not None and big._sort_split[1].tolist() == [0] * 5 + [1]
     idx = torch.zeros((4096, 2), dtype=torch.int32, device="cuda")
+    e2.sort(idx)
+    torch.cuda.synchronize()
+    big._sort_split, big._cstruct = None, None                                 # the same table WITHOUT the split is refused
     with pytest.raises(fmx._lib.FmxError) as ei:
         e2.sort(idx)
     assert ei.value.code == fmx._lib.ERR_UNSUPPORTED

@@ -1,0 +1,73 @@
+"""Per-rank work of the field-owner mode at G = 1, 2, 4, 8, measured on ONE GPU: rank 0's shard of the Criteo table, the
+global batch of G x 4096 samples, every kernel of a step timed back to back (HIP events, 40 launches each), plus the whole
+step through FieldOwnerFM at G = 1 (host cost included).  The collectives are not part of this: DESIGN.md adds them."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "fm-for-online-recommendation_amd"))
+import numpy as np, torch, fmx, bench
+from fmx.owner import FieldOwnerFM, HipOwnerBackend
+dev = torch.device("cuda")
+hyper = fmx.Hyper(**bench.HYPER)
+B = 4096
+work = torch.cuda.Stream()
+
+def timed(fn, n=40):
+    with torch.cuda.stream(work):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+for G in (1, 2, 4, 8):
+    GB = G * B
+    be = HipOwnerBackend(bench.CRITEO_SIZES, 16, hyper, "ftrl", "logits", 0, G, ftrl=bench.HYPER, max_local_batch=B)
+    w0 = torch.randn((be.table.n_rows, 16), device=dev) * 0.01
+    be.table.rows[:, :16] = w0
+    be.table.rows[:, be.table.z_offset:be.table.z_offset + 16] = fmx.table.ftrl_z_for_weight_torch(w0, be.table.ftrl)
+    cap = be.max_global_batch
+    n_sub = 1
+    while GB // n_sub > cap:
+        n_sub *= 2
+    GBs = GB // n_sub
+    idx_np, y_np = bench.synth_pool(4, GBs, bench.CRITEO_SIZES, 7)
+    idx_all = torch.from_numpy(idx_np).to(dev)
+    y = torch.from_numpy(y_np[0][:B // n_sub].copy()).to(dev)
+    own = [be.select(idx_all[j]) for j in range(4)]
+    t_sel = timed(lambda: be.select(idx_all[0]))
+    t_sort = timed(lambda: be.start_sort(own[0], 0, stream=work))
+    t_part = timed(lambda: be.partial_forward(own[1], stream=work))
+    parts = be.partial_forward(own[1])
+    mine = torch.stack([parts[:B // n_sub]] * G).contiguous()
+    t_fin = timed(lambda: be.finish(mine, y, 1.0 / GBs, stream=work))
+    rec = be.finish(mine, y, 1.0 / GBs)
+    rec_g = torch.cat([rec] * G).contiguous()
+    be.start_sort(own[1], 1)
+    t_upd = timed(lambda: be.update(own[1], rec_g, 1.0 / GBs, 1, stream=work))
+    print(f"G={G}: {len(be.fields)} fields on rank 0, global batch {GB} as {n_sub} exact step(s) of {GBs}: per exact step "
+          f"select {t_sel:.1f}  sort {t_sort:.1f} (ahead of time)  partial fwd {t_part:.1f}  finish {t_fin:.1f}  update {t_upd:.1f} us "
+          f"-> on the critical path {n_sub * (t_part + t_fin + t_upd):.1f} us of kernels per step of {GB} samples", flush=True)
+    del be
+
+be = HipOwnerBackend(bench.CRITEO_SIZES, 16, hyper, "ftrl", "logits", 0, 1, ftrl=bench.HYPER, max_local_batch=B)
+fo = FieldOwnerFM(be)
+idx_np, y_np = bench.synth_pool(8, B, bench.CRITEO_SIZES, 7)
+idx_pool, y_pool = torch.from_numpy(idx_np).to(dev), torch.from_numpy(y_np).to(dev)
+def run(n):
+    tokens = {0: fo.prefetch(idx_pool[0]), 1: fo.prefetch(idx_pool[1])}
+    for s in range(n):
+        fo.step(idx_pool[s % 8], y_pool[s % 8], tokens.pop(s, None))
+        if s + 2 < n:
+            tokens[s + 2] = fo.prefetch(idx_pool[(s + 2) % 8])
+with torch.cuda.stream(work):
+    run(20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(300)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print(f"FieldOwnerFM.step at G = 1 (no collectives), host included: {dt / 300 * 1e6:.1f} us/step = {300 * B / dt / 1e6:.1f} M samples/s")
