@@ -283,15 +283,28 @@ __device__ __forceinline__ void sort_field(const SortArgs &a, int f, uint32_t *s
   for (int r = 0; r < E; ++r) dst[(size_t)tid * E + r] = v[r];
 }
 
+// (unit, inner) of this block: units are spread round-robin over the 8 XCDs, the `n_inner` blocks of a unit share one
+// (blocks b and b + 8 share an XCD and its L2; placement is for speed only)
+__device__ __forceinline__ bool xcd_unit(int n_units, int n_inner, int &unit, int &inner) {
+  const int b = blockIdx.x, x = b & 7, s = b >> 3;
+  inner = s % n_inner;
+  unit = (s / n_inner) * 8 + x;
+  return unit < n_units;
+}
+
+// Grid: 8 * F * ceil(n_batches / 8) workgroups; the F workgroups of one batch sit on ONE XCD: each of them reads one
+// column of the batch's [B, Fi] index slab, i.e. 4 bytes of every 128-byte line, so a slab whose workgroups were dealt over
+// all eight XCDs was fetched from HBM by every one of them (21 MB per 8 batches against 5 MB of indices).
 template <int E>
 __global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
   extern __shared__ uint32_t sm[];
-  const int j = blockIdx.y;  // batch slot of this launch
+  int j, f;  // batch slot of this launch, sort field
+  if (!xcd_unit(a.n_batches, a.F, j, f)) return;
   if (j > 0 || a.pool_stride != 0) {
     a.idx += (size_t)((a.pool_first + j) % a.n_pool) * a.pool_stride;
     a.sorted += (size_t)j * a.sorted_stride;
   }
-  sort_field<E>(a, blockIdx.x, sm);
+  sort_field<E>(a, f, sm);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -321,14 +334,6 @@ struct ChunkArgs {
   int64_t runs_stride; // elements between the batches of one launch
   int32_t C;           // chunks per field = Bp / SORT_CHUNK
 };
-
-// (unit, inner) of this block: units are spread round-robin over the 8 XCDs, the `n_inner` blocks of a unit share one
-__device__ __forceinline__ bool xcd_unit(int n_units, int n_inner, int &unit, int &inner) {
-  const int b = blockIdx.x, x = b & 7, s = b >> 3;
-  inner = s % n_inner;
-  unit = (s / n_inner) * 8 + x;
-  return unit < n_units;
-}
 
 __global__ __launch_bounds__(SORT_CHUNK_THREADS) void k_sort_chunk(ChunkArgs a) {
   constexpr int E = SORT_CHUNK_E;
@@ -2369,7 +2374,7 @@ template <int E>
 void launch_sort(const SortArgs &a, hipStream_t st) {
   const int threads = a.Bp / E;
   const uint32_t lds = (uint32_t)(a.Bp * sizeof(uint32_t));
-  hipLaunchKernelGGL((k_sort_occ<E>), dim3(a.F, a.n_batches), dim3(threads), lds, st, a);
+  hipLaunchKernelGGL((k_sort_occ<E>), dim3(8 * a.F * ((a.n_batches + 7) / 8)), dim3(threads), lds, st, a);
 }
 
 int prepare_sort(int B) {

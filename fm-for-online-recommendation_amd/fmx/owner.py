@@ -52,6 +52,7 @@ class HipOwnerBackend:
     """The product backend: this rank's shard of the table (fmx.FlatTable over the owned fields) and an FMEngine on it."""
 
     N_SLOTS = 3   # batches whose indices may be gathered + sorted ahead of their update
+    takes_stream = True
 
     def __init__(self, feature_sizes, k, hyper, rule, loss, rank, world, layout=None, ftrl=None, device=None, max_local_batch=4096):
         self.rank, self.world, self.rule, self.loss, self.hyper = rank, world, rule, loss, hyper
@@ -90,10 +91,12 @@ class HipOwnerBackend:
         """parts_mine [G, B, 2 kp + 4] -> records [B, kp + 4] = (S, dlogit, loss, pad) of the local samples."""
         G, B = parts_mine.shape[0], parts_mine.shape[1]
         rec = self._buf("rec", (B, self.rec_out))
-        out = _lib.FwdOut()
-        base = rec.data_ptr()
-        out.S, out.dz, out.loss, out.sample_ld = base, base + 4 * self.kp, base + 4 * (self.kp + 1), self.rec_out
-        out.error = self.e.error.data_ptr()
+        out = self._bufs.get(("fwd_out", B))
+        if out is None:                              # the output struct only changes with the buffer it points at
+            out = self._bufs[("fwd_out", B)] = _lib.FwdOut()
+            base = rec.data_ptr()
+            out.S, out.dz, out.loss, out.sample_ld = base, base + 4 * self.kp, base + 4 * (self.kp + 1), self.rec_out
+            out.error = self.e.error.data_ptr()
         t = self.table
         _lib.check(self.e.lib.fmx_fm_forward_finish(self.hyper.ref(), t.bias.data_ptr(),
                                                    _lib.LAYOUT_WEIGHTS if t.layout == "weights" else _lib.LAYOUT_FTRL, t.kp,
@@ -230,11 +233,13 @@ class FieldOwnerFM:
             torch.cuda.current_stream(idx_local.device).wait_event(self._pf[1][slot])
         else:
             idx_own, slot = be.select(self._all_gather("idx", idx_local)), None
-        parts = be.partial_forward(idx_own)
+        # the launch stream is looked up once per step (torch.cuda.current_stream costs several microseconds per call)
+        kw = {"stream": torch.cuda.current_stream(idx_local.device)} if idx_local.is_cuda and getattr(be, "takes_stream", False) else {}
+        parts = be.partial_forward(idx_own, **kw)
         mine = self._all_to_all("parts", parts, B)
-        rec = be.finish(mine, y_local, inv_b)
+        rec = be.finish(mine, y_local, inv_b, **kw)
         rec_g = self._all_gather("rec", rec)
-        out = be.update(idx_own, rec_g, inv_b, slot) if slot is not None else be.update(idx_own, rec_g, inv_b)
+        out = be.update(idx_own, rec_g, inv_b, slot, **kw) if slot is not None else be.update(idx_own, rec_g, inv_b, **kw)
         if slot is not None:
-            self._pf[2][slot].record(torch.cuda.current_stream(idx_local.device))
+            self._pf[2][slot].record(kw.get("stream") or torch.cuda.current_stream(idx_local.device))
         return out
