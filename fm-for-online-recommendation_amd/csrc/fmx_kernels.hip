@@ -292,14 +292,19 @@ __device__ __forceinline__ bool xcd_unit(int n_units, int n_inner, int &unit, in
   return unit < n_units;
 }
 
-// Grid: 8 * F * ceil(n_batches / 8) workgroups; the F workgroups of one batch sit on ONE XCD: each of them reads one
+// Grid (launches of 8 or more batches): 8 * F * ceil(n_batches / 8) workgroups; the F workgroups of one batch sit on ONE XCD: each of them reads one
 // column of the batch's [B, Fi] index slab, i.e. 4 bytes of every 128-byte line, so a slab whose workgroups were dealt over
 // all eight XCDs was fetched from HBM by every one of them (21 MB per 8 batches against 5 MB of indices).
 template <int E>
 __global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
   extern __shared__ uint32_t sm[];
   int j, f;  // batch slot of this launch, sort field
-  if (!xcd_unit(a.n_batches, a.F, j, f)) return;
+  if (a.n_batches >= 8) {
+    if (!xcd_unit(a.n_batches, a.F, j, f)) return;
+  } else {  // few batches: all their workgroups on one or a few XCDs would leave most of the chip idle (39 workgroups on 32 CUs)
+    j = blockIdx.x / a.F;
+    f = blockIdx.x - j * a.F;
+  }
   if (j > 0 || a.pool_stride != 0) {
     a.idx += (size_t)((a.pool_first + j) % a.n_pool) * a.pool_stride;
     a.sorted += (size_t)j * a.sorted_stride;
@@ -2374,7 +2379,8 @@ template <int E>
 void launch_sort(const SortArgs &a, hipStream_t st) {
   const int threads = a.Bp / E;
   const uint32_t lds = (uint32_t)(a.Bp * sizeof(uint32_t));
-  hipLaunchKernelGGL((k_sort_occ<E>), dim3(8 * a.F * ((a.n_batches + 7) / 8)), dim3(threads), lds, st, a);
+  const int grid = a.n_batches >= 8 ? 8 * a.F * ((a.n_batches + 7) / 8) : a.F * a.n_batches;
+  hipLaunchKernelGGL((k_sort_occ<E>), dim3(grid), dim3(threads), lds, st, a);
 }
 
 int prepare_sort(int B) {

@@ -16,7 +16,7 @@ for i in 1 2 3; do
   timeout -k 10 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tee -a $out/${tag}_bench20.json | \
     python -c "import sys,json; d=json.loads(sys.stdin.read()); print('20-step run: %.1f M samples/s, %.2f us/step' % (d['value']/1e6, d['ms_per_step']*1e3))" || exit 1
 done
-timeout -k 10 400 python bench.py --no-cpu-baseline 2>$out/${tag}_bench.err | tee $out/${tag}_bench.json | \
+timeout -k 10 400 python bench.py 2>$out/${tag}_bench.err | tee $out/${tag}_bench.json | \
   python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
