@@ -2118,6 +2118,8 @@ struct Tune {
   int sort_ahead = 8;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..8)
   int fused_step = 0;    // FMX_FUSED_STEP=1 / fmx_set_option("fused_step", 1): fmx_fm_stream launches update(s) + forward(s + 1) as ONE
                          // launch (k_fm_fused) instead of separately; identical bits; measured slower, so off
+  int mlp_chain = 1;          // FMX_MLP_CHAIN=0 / fmx_set_option("mlp_chain", 0): fmx_mlp_section as separate GEMM launches
+                              // (forward x L, loss, dgrad x L) instead of k_mlp_chain; same results up to summation order
   int fused_debug = 0;        // FMX_FUSED_DEBUG (timing experiments, wrong results): 1 no forward workgroups, 2 forward does not wait
   int fused_wpb = 4;          // FMX_FUSED_WPB: waves per workgroup of k_fm_fused (4 or 16)
   int fused_first_sleep = 64; // FMX_FUSED_FIRST_SLEEP: s_sleep units (64 clocks) a forward workgroup waits before its first poll
@@ -2138,6 +2140,7 @@ Tune &tune() {
     if (const char *e = getenv("FMX_SORT_CHUNKED")) x.sort_chunked = atoi(e);
     if (const char *e = getenv("FMX_FUSED_STEP")) x.fused_step = atoi(e);
     if (const char *e = getenv("FMX_FUSED_DEBUG")) x.fused_debug = atoi(e);
+    if (const char *e = getenv("FMX_MLP_CHAIN")) x.mlp_chain = atoi(e);
     if (const char *e = getenv("FMX_FUSED_WPB")) x.fused_wpb = atoi(e) == 16 ? 16 : 4;
     if (const char *e = getenv("FMX_FUSED_FIRST_SLEEP")) x.fused_first_sleep = atoi(e);
     if (const char *e = getenv("FMX_FUSED_POLL_SLEEP")) x.fused_poll_sleep = atoi(e);
@@ -2683,6 +2686,7 @@ int fmx_set_option(const char *name, int value) {
   else if (!strcmp(name, "online_persistent")) slot = &t.online_persistent;
   else if (!strcmp(name, "sort_chunked")) slot = &t.sort_chunked;
   else if (!strcmp(name, "fused_step")) slot = &t.fused_step;
+  else if (!strcmp(name, "mlp_chain")) slot = &t.mlp_chain;
   else return fail(FMX_ERR_ARG, "fmx_set_option: unknown option '%s'", name);
   const int old = *slot;
   *slot = value;
@@ -3325,9 +3329,10 @@ int64_t fmx_mlp_section_workspace_bytes(const fmx_mlp_t *mlp, int32_t B) {
 // the backward of the mini-batch MLP from dH_{L-1} (already in w.dH): the dgrad chain (with `rowadd_l` [L, B] added to
 // layer l's dH before its mask when given: Hedge), dL/dbi into gbi_out when given, every layer's dW | db in one launch,
 // then the fixed-order reduction into `grads` (+ optional SGD, + the mean of w.loss_b into loss_out when given)
+// skip_dgrad: k_mlp_chain has already produced every dH_l and gbi; only the weight gradients and their reduction remain
 static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const float *bi, int32_t ld_bi, int32_t B,
                              const float *rowadd_l, float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply,
-                             float *loss_out, float inv_b, hipStream_t st) {
+                             float *loss_out, float inv_b, hipStream_t st, bool skip_dgrad = false) {
   const int L = mlp->n_layers, H = mlp->hidden, k = mlp->k;
   const size_t act = align_up((size_t)B * H * 4, 256) / 4;
   const float *Wl[MLP_BIG_MAX_L];
@@ -3389,6 +3394,7 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
       if ((in + G_BN - 1) / G_BN > wgx) wgx = (in + G_BN - 1) / G_BN;
       ++wb.n;
     }
+    if (skip_dgrad) continue;
     if (l == 0 && !gbi_out) continue;  // nothing below the first layer wants a gradient (Hedge leaves the tables alone)
     GemmArgs g = base_args();
     g.A = cur;
@@ -3470,6 +3476,46 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
   const MlpBigWs w = mlp_big_carve(mlp, B, workspace);
   const int L = mlp->n_layers, H = mlp->hidden;
   const size_t act = align_up((size_t)B * H * 4, 256) / 4;
+  if (tune().mlp_chain && chain_eligible(mlp)) {
+    // forward, loss and the dgrad chain in ONE launch (k_mlp_chain), then the weight gradients and their reduction
+    ChainArgs c;
+    c.params = mlp->params;
+    c.bi = bi;
+    c.base = base;
+    c.y = y;
+    c.acts = w.acts;
+    c.dH = w.dH;
+    c.act_stride = act;
+    c.logit_out = logit_out;
+    c.dz_out = dz_out;
+    c.loss_b = w.loss_b;
+    c.gbi_out = gbi_out;
+    long long o = 0;
+    for (int l = 0; l < L; ++l) {
+      const int in = l == 0 ? mlp->k : H;
+      c.w_off[l] = o;
+      c.b_off[l] = o + (long long)H * in;
+      o += (long long)H * in + H;
+    }
+    c.B = B;
+    c.k = mlp->k;
+    c.H = H;
+    c.L = L;
+    c.ld_bi = ld_bi;
+    c.ld_gbi = ld_gbi;
+    c.loss_kind = loss_kind;
+    c.inv_b = inv_b;
+    c.stamps = tune().mlp_chain == 2 ? reinterpret_cast<unsigned long long *>(w.loss_lb) : nullptr;  // debug: tools/mlp_chain_stamps.py
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)chain_lds_bytes(CH_MAXH));
+      raised = true;
+    }
+    hipLaunchKernelGGL(k_mlp_chain, dim3((B + CH_R - 1) / CH_R), dim3(256), chain_lds_bytes(H), st, c);
+    mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st, true);
+    return check_launch("fmx_mlp_section (k_mlp_chain)");
+  }
   mlp_big_forward(mlp, w, bi, ld_bi, B, st);
   {  // ---- loss, dL/dlogit, dH_L ----
     MlpLossArgs a;
