@@ -329,8 +329,8 @@ __global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
 // the workgroups of 32 fields) sit on ONE XCD, so the slab is fetched from HBM once instead of once per XCD; likewise
 // the C merge workgroups of a field read the same Bp words.  Placement is for speed only.
 constexpr int SORT_CHUNK = 1024, SORT_CHUNK_E = 4, SORT_CHUNK_THREADS = SORT_CHUNK / SORT_CHUNK_E;
-// from this width on the chunked form is the faster one (MI355X, Criteo vocabulary, one batch per launch: 4,096: 15 vs 18.6 us
-// -- but 8 batches per launch 36 vs 31, the total VALU work being the same; 8,192: 20 vs 35; 16,384: 35 vs 74)
+// from this width on the chunked form is the faster one for ONE batch per launch (MI355X, Criteo vocabulary: 4,096: 17.5 vs
+// 18.5 us; 8,192: 24 vs 36; 16,384: 60 vs 74; 32,768 x 6 fields: 58 us) -- launches of 8 batches: 29 vs 27, 71 vs 55, 294 vs 118
 constexpr int SORT_CHUNKED_MIN_WIDTH = 8192;
 
 struct ChunkArgs {
@@ -2440,7 +2440,11 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
   a.Fi = table->n_fields;
   a.Bp = fmx_sorted_width(B);
   a.bbits = fmx_sorted_bbits(B);
-  if (a.Bp >= (tune().sort_chunked > 1 ? 2 * SORT_CHUNK : SORT_CHUNKED_MIN_WIDTH) && tune().sort_chunked && runs) {
+  // the chunked form wins on LATENCY (one or two batches per launch: the prefetched global sorts of the multi-GPU modes, a
+  // single step); a launch of many batches fills the chip either way and the rank merge then costs more work than the
+  // bitonic stages it replaces (8 batches of 16,384: 294 vs 118 us)
+  if (a.Bp >= (tune().sort_chunked > 1 ? 2 * SORT_CHUNK : SORT_CHUNKED_MIN_WIDTH) && tune().sort_chunked && runs &&
+      (a.n_batches <= 2 || tune().sort_chunked > 1)) {
     // chunk sort + rank merge, spread over the chip (k_sort_chunk / k_sort_merge)
     if (int rc = prepare_merge(a.Bp)) return rc;
     ChunkArgs c;
