@@ -378,6 +378,63 @@ def test_deep_trainer_step_vs_oracle(name, native):
     assert_state_close(got, ref, {kk: sd0[kk] for kk in ref}, what=f"{name} sgd step")
 
 
+def test_deep_trainer_full_size_step_vs_oracle():
+    """BASELINE configs[3] END TO END at its full size: one online DeepFM step (Criteo vocabulary R = 1,006,628, k = 16,
+    3 x 256 relu MLP, B = 4096, SGD lr 1e-3) through fmx.DeepFMTrainer -- sort, forward, the MLP section (k_mlp_chain +
+    wgrad + reduce), the row-reduced table update with dL/dbi, SGD on the MLP -- against the oracle's class step from the
+    same parameters.  (The small-fixture form of this test is test_deep_trainer_step_vs_oracle.)"""
+    import fmx
+    import torch.nn as nn
+    sizes = [63, 113, 126, 51, 224, 148, 100, 79, 104, 9, 32, 57, 82, 1457, 555, 176373, 129683, 305, 19, 11887, 632, 3, 41738,
+             5170, 175446, 3170, 27, 11356, 165602, 10, 4641, 2030, 4, 172761, 18, 15, 57903, 86, 44549]
+    k, L, H, B, lr = 16, 3, 256, 4096, 1e-3
+    rng = np.random.default_rng(11)
+    sd0 = {"bias": np.float32(0.1), "n": np.float32(lr)}
+    for i, sz in enumerate(sizes):
+        sd0[f"first_order_embeddings.{i}.weight"] = (rng.normal(size=(sz, 1)) * 0.1).astype(np.float32)
+        sd0[f"second_order_embeddings.{i}.weight"] = (rng.normal(size=(sz, k)) * 0.1).astype(np.float32)
+    for j in range(L):
+        fan = k if j == 0 else H
+        sd0[f"hidden_layers.{j}.weight"] = (rng.normal(size=(H, fan)) / np.sqrt(fan)).astype(np.float32)
+        sd0[f"hidden_layers.{j}.bias"] = (rng.normal(size=H) * 0.05).astype(np.float32)
+    Xi = np.stack([rng.integers(0, sz, size=B) for sz in sizes], axis=1)
+    Y = (rng.uniform(size=B) < 0.3).astype(np.float32)
+    F_ = len(sizes)
+    table = fmx.FlatTable(sizes, k, layout="weights")
+    table.load_reference([sd0[f"first_order_embeddings.{i}.weight"] for i in range(F_)],
+                         [sd0[f"second_order_embeddings.{i}.weight"] for i in range(F_)])
+    table.set_bias_weight(float(sd0["bias"]))
+    eng = fmx.FMEngine(table, max_batch=B)
+    layers = [nn.Linear(k if j == 0 else H, H).cuda() for j in range(L)]
+    with torch.no_grad():
+        for j, layer in enumerate(layers):
+            layer.weight.copy_(torch.from_numpy(sd0[f"hidden_layers.{j}.weight"]))
+            layer.bias.copy_(torch.from_numpy(sd0[f"hidden_layers.{j}.bias"]))
+    tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=lr), "sgd"), layers, k, table.kp, mlp_lr=lr, fm_term=True,
+                           loss=orc.LOSS_KIND[("DeepFMAdam", "fit")], native_mlp=True)
+    assert tr.native
+    idx_d, _, y_d = eng.to_device(Xi.astype(np.int32), None, Y)
+    tr.step(idx_d, y_d)
+    torch.cuda.synchronize()
+    eng.check_error_flag()
+    om = orc.OracleModel("DeepFMAdam", sd0, update_rule="sgd")
+    om.fit(Xi, np.ones(Xi.shape, dtype=np.float32), Y)
+    ref = om.state_dict()
+    first, second = table.export_reference()
+    got = {"bias": table.bias_weight().cpu().numpy()}
+    for i in range(F_):
+        got[f"first_order_embeddings.{i}.weight"] = first[i].numpy()
+        got[f"second_order_embeddings.{i}.weight"] = second[i].numpy()
+    for j, layer in enumerate(layers):
+        got[f"hidden_layers.{j}.weight"] = layer.weight.detach().cpu().numpy()
+        got[f"hidden_layers.{j}.bias"] = layer.bias.detach().cpu().numpy()
+    ref = {kk: v for kk, v in ref.items() if kk in got}
+    assert_state_close(got, ref, {kk: sd0[kk] for kk in ref}, what="DeepFM 3x256 full-size sgd step")
+    # the step did move every kind of parameter
+    assert np.abs(got["hidden_layers.1.weight"] - sd0["hidden_layers.1.weight"]).max() > 0
+    assert np.abs(got["second_order_embeddings.15.weight"] - sd0["second_order_embeddings.15.weight"]).max() > 0
+
+
 def test_config4_nfm_hedge_on_a_frappe_shaped_10m_row_table():
     """BASELINE.json configs[4] as a parity case: online NFM + Hedge backprop (reference nfm_onn.py:111-156) on
     Frappe-shaped input -- 10 one-hot fields over 10 M embedding rows, k = 16, L = 3 -- in the reference's online protocol
