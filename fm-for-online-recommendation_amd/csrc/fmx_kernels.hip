@@ -141,6 +141,11 @@ struct SortArgs {
   int32_t *error;
   int32_t B, F, Bp, bbits;  // F: number of SORT fields
   int32_t Fi;               // number of fields = columns of idx
+  // row prefetch (null: off): the sort runs batches ahead of the steps on a side stream and is the first to know which rows
+  // a batch will touch -- it requests one word of each of the row's lines, so that a row nobody has touched yet comes from HBM
+  // here and not on the critical path of k_fm_forward / k_fm_update (a fresh process, tables beyond the Infinity Cache)
+  const float *pf_rows;
+  int32_t pf_stride, pf_zoff;  // floats; pf_zoff > 0: the row has a second line (FTRL z | n)
 };
 
 // lane ^ M exchanges without the LDS crossbar (ds_bpermute made the sort LDS-pipe bound): DPP for M = 1, 2, 4, 8,
@@ -234,14 +239,22 @@ __device__ __forceinline__ void load_composites(const SortArgs &a, int f, int i0
     li[r] = (uint32_t)a.idx[(size_t)(i < a.B ? i : a.B - 1) * a.Fi + col];
   }
   bool bad = false;
+  float pf = 0.f;
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const int i = i0 + r;
     const uint32_t lp = li[r] - base;  // wraps to a huge value below the piece
-    v[r] = (i < a.B && lp < piece_rows) ? ((lp << a.bbits) | (uint32_t)i) : SENT;
+    const bool mine = i < a.B && lp < piece_rows;
+    v[r] = mine ? ((lp << a.bbits) | (uint32_t)i) : SENT;
     bad = bad || (i < a.B && li[r] >= field_rows);
+    if (a.pf_rows && mine) {  // touch the row's line(s); the values only keep the loads alive
+      const float *rp = a.pf_rows + (size_t)(a.soff[f] + lp) * a.pf_stride;
+      pf += __builtin_nontemporal_load(rp);
+      if (a.pf_zoff > 0) pf += __builtin_nontemporal_load(rp + a.pf_zoff);
+    }
   }
   if (bad && a.error) *a.error = 1;
+  if (a.pf_rows && __float_as_uint(pf) == 0x7FBADBADu && a.error) *a.error = 0x7FFFFFFF;  // never true in practice: keeps the prefetch loads
 }
 
 // Device body of the occurrence sort of ONE field (the calling workgroup: nt threads, nt * E == Bp): the full bitonic
@@ -2118,6 +2131,10 @@ struct Tune {
   int sort_ahead = 8;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..8)
   int fused_step = 0;    // FMX_FUSED_STEP=1 / fmx_set_option("fused_step", 1): fmx_fm_stream launches update(s) + forward(s + 1) as ONE
                          // launch (k_fm_fused) instead of separately; identical bits; measured slower, so off
+  int sort_prefetch = 0;      // FMX_SORT_PREFETCH=1 / fmx_set_option("sort_prefetch", 1): the sort touches the rows of its batch (a
+                              // software prefetch from the stage that runs ahead).  Measured SLOWER -- fresh 20-step run 39.4 vs
+                              // 33.5 us/step, steady state 28.2 vs 24.0: the sort waits for its 8 extra loads per thread and the
+                              // two streams then fight for the same lines -- so off
   int mlp_chain = 1;          // FMX_MLP_CHAIN=0 / fmx_set_option("mlp_chain", 0): fmx_mlp_section as separate GEMM launches
                               // (forward x L, loss, dgrad x L) instead of k_mlp_chain; same results up to summation order
   int fused_debug = 0;        // FMX_FUSED_DEBUG (timing experiments, wrong results): 1 no forward workgroups, 2 forward does not wait
@@ -2141,6 +2158,7 @@ Tune &tune() {
     if (const char *e = getenv("FMX_FUSED_STEP")) x.fused_step = atoi(e);
     if (const char *e = getenv("FMX_FUSED_DEBUG")) x.fused_debug = atoi(e);
     if (const char *e = getenv("FMX_MLP_CHAIN")) x.mlp_chain = atoi(e);
+    if (const char *e = getenv("FMX_SORT_PREFETCH")) x.sort_prefetch = atoi(e);
     if (const char *e = getenv("FMX_FUSED_WPB")) x.fused_wpb = atoi(e) == 16 ? 16 : 4;
     if (const char *e = getenv("FMX_FUSED_FIRST_SLEEP")) x.fused_first_sleep = atoi(e);
     if (const char *e = getenv("FMX_FUSED_POLL_SLEEP")) x.fused_poll_sleep = atoi(e);
@@ -2440,6 +2458,9 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
   a.Fi = table->n_fields;
   a.Bp = fmx_sorted_width(B);
   a.bbits = fmx_sorted_bbits(B);
+  a.pf_rows = tune().sort_prefetch ? table->rows : nullptr;
+  a.pf_stride = table->row_stride;
+  a.pf_zoff = table->layout == FMX_LAYOUT_FTRL ? table->z_offset : 0;
   // the chunked form wins on LATENCY (one or two batches per launch: the prefetched global sorts of the multi-GPU modes, a
   // single step); a launch of many batches fills the chip either way and the rank merge then costs more work than the
   // bitonic stages it replaces (8 batches of 16,384: 294 vs 118 us)
@@ -2691,6 +2712,7 @@ int fmx_set_option(const char *name, int value) {
   else if (!strcmp(name, "sort_chunked")) slot = &t.sort_chunked;
   else if (!strcmp(name, "fused_step")) slot = &t.fused_step;
   else if (!strcmp(name, "mlp_chain")) slot = &t.mlp_chain;
+  else if (!strcmp(name, "sort_prefetch")) slot = &t.sort_prefetch;
   else return fail(FMX_ERR_ARG, "fmx_set_option: unknown option '%s'", name);
   const int old = *slot;
   *slot = value;

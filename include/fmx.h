@@ -140,6 +140,9 @@ const char *fmx_last_error_string(void);
  *                                chunks spread over the chip, stable rank merge) from 8,192 composites per field on; 2: from 2,048 on.
  *   "fused_step"   (default 0)  1 / 2: fmx_fm_stream launches update(s) + forward(s + 1) as ONE launch (k_fm_fused; 1: one
  *                                agent-scope acquire per forward workgroup and plain gather loads, 2: sc1 gather loads).
+ *   "mlp_chain"    (default 1)  0: fmx_mlp_section as separate GEMM launches instead of k_mlp_chain (forward + loss + dgrad chain
+ *                                in one launch); same results up to summation order.
+ *   "sort_prefetch" (default 0) 1: the occurrence sort also touches the rows of its batch (measured slower).
  *   "online_persistent" (default 1)  0: fmx_online_run_mlp as per-sample launches instead of one workgroup walking the stream. */
 int fmx_set_option(const char *name, int value);
 
