@@ -2189,6 +2189,7 @@ struct Workspace {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 #include "fmx_mlp_gemm.inc"
+#include "fmx_sftrl.inc"
 
 Workspace carve(const fmx_table_t *t, int B, void *base) {
   const size_t F = (size_t)n_sort_fields(t), Bp = (size_t)fmx_sorted_width(B), tiles = Bp >> 6;
@@ -3606,6 +3607,44 @@ int fmx_mlp_hedge_section(const fmx_mlp_t *mlp, float lr, float hedge_b, float h
     hipLaunchKernelGGL(k_mlp_hedge_alpha, dim3(1), dim3(256), 0, st, a);
   }
   return check_launch("fmx_mlp_hedge_section");
+}
+
+int fmx_sftrl_run(const double *X, const double *y, int32_t N, int32_t D, int32_t d, int32_t m, double eta, double thres,
+                  int32_t task, double *BP, double *BN, int32_t *counts, double *w, double *g_w, double *pred_out,
+                  int32_t *status, fmx_stream_t stream) {
+  if (!X || !y || !BP || !BN || !counts || !pred_out || !status) return fail(FMX_ERR_ARG, "fmx_sftrl_run: null argument");
+  if ((w == nullptr) != (g_w == nullptr)) return fail(FMX_ERR_ARG, "fmx_sftrl_run: w and g_w go together");
+  if (N < 0 || D < 1 || d < 1 || d > D || m < 1) return fail(FMX_ERR_ARG, "fmx_sftrl_run: bad sizes");
+  if (task != 0 && task != 1) return fail(FMX_ERR_ARG, "fmx_sftrl_run: task must be 0 (cls) or 1 (reg)");
+  if (d > SF_MAX_D || 2 * m > SF_MAX_C || D > 4096)
+    return fail(FMX_ERR_UNSUPPORTED, "fmx_sftrl_run: needs sketch dim <= %d, 2 m <= %d, features <= 4096 (got %d, %d, %d)", SF_MAX_D,
+                SF_MAX_C, d, 2 * m, D);
+  if (N == 0) return FMX_OK;
+  SftrlArgs a;
+  a.X = X;
+  a.y = y;
+  a.BP = BP;
+  a.BN = BN;
+  a.counts = counts;
+  a.w = w;
+  a.g_w = g_w;
+  a.pred = pred_out;
+  a.status = status;
+  a.eta = eta;
+  a.thres = thres;
+  a.N = N;
+  a.D = D;
+  a.d = d;
+  a.m = m;
+  a.cls = task == 0;
+  const size_t lds = ((size_t)2 * d * 2 * m + 2 * (size_t)d * d + d + D) * sizeof(double) + (size_t)d * sizeof(int) + 16;
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sftrl_online), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    raised = true;
+  }
+  hipLaunchKernelGGL(k_sftrl_online, dim3(1), dim3(64), lds, static_cast<hipStream_t>(stream), a);
+  return check_launch("k_sftrl_online");
 }
 
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream) {

@@ -1,7 +1,10 @@
 """SFTRL_CCFM -- drop-in for reference models/models_online/SFTRL_CCFM.py:18-121 (sketched FTRL, convex-concave FM).
 
 y_hat = ||BP^T x||^2 - ||BN^T x||^2 (:42-44); the gradient sign s picks the sketch: s <= 0 appends sqrt(-eta s) x to
-BP, s > 0 appends sqrt(eta s) x to BN (:77-121).  Host fp64 like the reference's CPU path; see _sketch.py."""
+BP, s > 0 appends sqrt(eta s) x to BN (:77-121).  fp64 like the reference.  device="host" (the default, like the
+reference's CPU path; see _sketch.py) or device="gpu": the whole stream in one fmx_sftrl_run launch (include/fmx.h;
+one wavefront, sketches in LDS, the shrink as a Jacobi eigen-decomposition of B B^T -- same B B^T, predictions and
+counts, columns of B up to sign).  The gpu path never falls back: outside the kernel's limits it raises."""
 import time
 
 import numpy as np
@@ -16,8 +19,11 @@ Tensor_type = torch.DoubleTensor
 class SFTRL_CCFM(FM_Base):
     _linear_term = False
 
-    def __init__(self, inputs_matrix, outputs, task, learning_rate, num_feature):
+    def __init__(self, inputs_matrix, outputs, task, learning_rate, num_feature, device="host"):
         super(SFTRL_CCFM, self).__init__(inputs_matrix, outputs, task, learning_rate, num_feature)
+        if device not in ("host", "gpu"):
+            raise ValueError("device must be 'host' or 'gpu'")
+        self.device = device
         self.model_name = "SFTRL_CCFM"
         self.row_count_p = 0
         self.row_count_n = 0
@@ -38,6 +44,11 @@ class SFTRL_CCFM(FM_Base):
         X = self.At.t().contiguous().numpy().astype(np.float64, copy=False)
         y = np.asarray(self.b.reshape(-1).numpy(), dtype=np.float64)
         d = self._sketch_dim()
+        if self.device == "gpu":
+            preds = self._online_learning_gpu(X, y, d, cls)
+            end = time.time()
+            print("learning time : %f " % (end - start))
+            return preds, y.copy(), (end - start)
         P, N = Sketch(d, self.m, self._thres), Sketch(d, self.m, self._thres)
         P.B, P.count = self.BT_P.numpy().copy(), self.row_count_p
         N.B, N.count = self.BT_N.numpy().copy(), self.row_count_n
@@ -77,6 +88,39 @@ class SFTRL_CCFM(FM_Base):
         end = time.time()
         print("learning time : %f " % (end - start))
         return preds, y.copy(), (end - start)
+
+    def _online_learning_gpu(self, X, y, d, cls):
+        """The same stream through fmx_sftrl_run; state (sketches, counts, linear term) is read and written back."""
+        import ctypes as C
+
+        from fmx import _lib
+        lib = _lib.load()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        n, D = X.shape
+        Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+        BP, BN = self.BT_P.to(dev).contiguous(), self.BT_N.to(dev).contiguous()
+        counts = torch.tensor([self.row_count_p, self.row_count_n], dtype=torch.int32, device=dev)
+        w = g_w = None
+        if self._linear_term:
+            w, g_w = self.w.reshape(-1).to(dev).contiguous(), self.g_w.reshape(-1).to(dev).contiguous()
+        pred = torch.empty(n, dtype=torch.float64, device=dev)
+        status = torch.zeros(2, dtype=torch.int32, device=dev)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _lib.check(lib.fmx_sftrl_run(ptr(Xd), ptr(yd), n, D, d, self.m, float(self.eta), float(self._thres), 0 if cls else 1,
+                                     ptr(BP), ptr(BN), ptr(counts), ptr(w), ptr(g_w), ptr(pred), ptr(status),
+                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        st = status.cpu()
+        if int(st[0]) == 1:
+            raise ValueError("Nan contained")
+        c = counts.cpu()
+        self.BT_P, self.row_count_p = BP.cpu(), int(c[0])
+        self.BT_N, self.row_count_n = BN.cpu(), int(c[1])
+        if self._linear_term:
+            self.w, self.g_w = w.cpu().reshape(-1, 1), g_w.cpu().reshape(-1, 1)
+        p = pred.cpu().numpy()
+        for idx in range(0, n, 1000):
+            print(" %d th : pred %f , real %f " % (idx, p[idx], y[idx]))
+        return p.reshape((n,) + self._pred_shape(cls))
 
     def _pred_shape(self, cls):
         return (1,) if cls else ()

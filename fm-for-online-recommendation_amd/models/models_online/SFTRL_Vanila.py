@@ -13,8 +13,8 @@ Tensor_type = torch.DoubleTensor
 class SFTRL_Vanila(SFTRL_CCFM):
     _linear_term = True
 
-    def __init__(self, inputs_matrix, outputs, task, learning_rate, num_feature):
-        super(SFTRL_Vanila, self).__init__(inputs_matrix, outputs, task, learning_rate, num_feature)
+    def __init__(self, inputs_matrix, outputs, task, learning_rate, num_feature, device="host"):
+        super(SFTRL_Vanila, self).__init__(inputs_matrix, outputs, task, learning_rate, num_feature, device=device)
         self.model_name = "SFTRL_Vanila"
         self.w = Tensor_type(np.zeros([self.num_feature, 1]))
         self.g_w = Tensor_type(np.zeros([self.num_feature, 1]))

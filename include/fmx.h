@@ -333,6 +333,20 @@ int fmx_mlp_hedge_section(const fmx_mlp_t *mlp, float lr, float hedge_b, float h
                           int32_t ld_bi, const float *base, const float *y, int32_t B, void *workspace, float *grads,
                           float *losses_out, fmx_stream_t stream);
 
+/* The sketched-FTRL family on a device-resident stream (hot path B's sketch classes): for every
+ * sample predict y_hat = ||BP^T x||^2 - ||BN^T x||^2 (+ w^T x), then append sqrt(eta |s|) x to the sketch the gradient sign s
+ * picks and shrink a full sketch (frequent directions).  fp64 like the reference, strictly sequential: ONE wavefront walks the
+ * stream with both sketches in LDS; the shrink is a Jacobi eigen-decomposition of the d x d Gram matrix (same B B^T as the
+ * reference's SVD of B^T B; the columns of B may differ by sign).
+ *   X [N, D], y [N] fp64; the first d features enter the sketches (d = D: SFTRL_CCFM; d = D - 1 with w, g_w [D]: SFTRL_Vanila)
+ *   BP, BN [d, 2 m] row-major and counts [2] (columns in use) are read and written back; task 0 = cls (+-1 predictions), 1 = reg
+ *   status [2]: status[0] = 1 when the prediction of sample status[1] was NaN (the run stops there)
+ * Limits: d <= 32, 2 m <= 128, D <= 4096, else FMX_ERR_UNSUPPORTED (the caller's host path).
+ * Replaces: SFTRL_CCFM.online_learning / _GFD (reference models/models_online/SFTRL_CCFM.py:30-121), SFTRL_Vanila.py:30-130. */
+int fmx_sftrl_run(const double *X, const double *y, int32_t N, int32_t D, int32_t d, int32_t m, double eta, double thres,
+                  int32_t task, double *BP, double *BN, int32_t *counts, double *w, double *g_w, double *pred_out,
+                  int32_t *status, fmx_stream_t stream);
+
 /* Streaming read of `bytes` (multiple of 16) with 16-byte loads; sink [1] receives a checksum so the loads stay
  * live.  Used by bench.py to measure the HBM-read ceiling on the same GPU in the same run. */
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream);
