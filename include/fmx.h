@@ -142,7 +142,11 @@ const char *fmx_last_error_string(void);
  *                                agent-scope acquire per forward workgroup and plain gather loads, 2: sc1 gather loads).
  *   "mlp_chain"    (default 1)  0: fmx_mlp_section as separate GEMM launches instead of k_mlp_chain (forward + loss + dgrad chain
  *                                in one launch); same results up to summation order.
+ *   "wgrad_reduce" (default 1)  1: the batch-split partials of the MLP's weight-gradient launch are summed by each tile's
+ *                                last-arriving workgroup (inside k_mlp_wgrad); 0: by a second launch (k_mlp_reduce).
  *   "sort_prefetch" (default 0) 1: the occurrence sort also touches the rows of its batch (measured slower).
+ *   "table_prewarm" (default 0) n > 0: fmx_fm_stream starts with one streaming read of the table by n workgroups on a third
+ *                                stream (measured: no gain).
  *   "online_persistent" (default 1)  0: fmx_online_run_mlp as per-sample launches instead of one workgroup walking the stream. */
 int fmx_set_option(const char *name, int value);
 
@@ -341,7 +345,7 @@ int fmx_mlp_hedge_section(const fmx_mlp_t *mlp, float lr, float hedge_b, float h
  *   X [N, D], y [N] fp64; the first d features enter the sketches (d = D: SFTRL_CCFM; d = D - 1 with w, g_w [D]: SFTRL_Vanila)
  *   BP, BN [d, 2 m] row-major and counts [2] (columns in use) are read and written back; task 0 = cls (+-1 predictions), 1 = reg
  *   status [2]: status[0] = 1 when the prediction of sample status[1] was NaN (the run stops there)
- * Limits: d <= 32, 2 m <= 128, D <= 4096, else FMX_ERR_UNSUPPORTED (the caller's host path).
+ * Limits: d <= 32, 2 m <= 128, D <= 64, else FMX_ERR_UNSUPPORTED (the caller's host path).
  * Replaces: SFTRL_CCFM.online_learning / _GFD (reference models/models_online/SFTRL_CCFM.py:30-121), SFTRL_Vanila.py:30-130. */
 int fmx_sftrl_run(const double *X, const double *y, int32_t N, int32_t D, int32_t d, int32_t m, double eta, double thres,
                   int32_t task, double *BP, double *BN, int32_t *counts, double *w, double *g_w, double *pred_out,
