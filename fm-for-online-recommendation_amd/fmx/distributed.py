@@ -12,6 +12,8 @@ dense network on top (DeepFM / NFM) adds one fused all-reduce of its gradients.
 The compute behind a step is a small backend interface so that the sharding / gather logic can be exercised on CPU
 with the gloo backend in tests (tests inject an oracle-backed backend; the product has only the HIP one).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -96,7 +98,7 @@ class DataParallelFM:
 
     def _gathered(self, name, local):
         """all_gather `local` ([B, ...] contiguous) into a rank-major [G*B, ...] buffer."""
-        if self.world == 1:
+        if self.world == 1 and os.environ.get("FMX_FORCE_COLLECTIVES") != "1":  # (=1: tools/nccl_world1_check.py)
             return local
         key = (name, local.shape[0])
         out = self._bufs.get(key)

@@ -24,6 +24,7 @@ The compute behind a step is a small backend interface so that the sharding / ex
 tests (an oracle-backed backend injected there; the product has only the HIP one).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -143,6 +144,9 @@ class FieldOwnerFM:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._gloo = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        # FMX_FORCE_COLLECTIVES=1: issue the collectives even with one rank (tools/nccl_world1_check.py: the RCCL calls of a
+        # step on a one-GPU box)
+        self._force = dist.is_initialized() and os.environ.get("FMX_FORCE_COLLECTIVES") == "1"
         self._bufs = {}
         self._pref, self._next_slot, self._pf = {}, 0, None
 
@@ -154,7 +158,7 @@ class FieldOwnerFM:
         return t
 
     def _all_gather(self, name, local):
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return local
         out = self._out(name, (self.world * local.shape[0],) + tuple(local.shape[1:]), local)
         if self._gloo and local.is_cuda:
@@ -167,7 +171,7 @@ class FieldOwnerFM:
 
     def _all_to_all(self, name, parts, B):
         """parts [G B, R] (rank-major samples) -> [G, B, R]: block r = rank r's records of THIS rank's samples."""
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return parts.view(1, B, parts.shape[1])
         out = self._out(name, (self.world * B, parts.shape[1]), parts)
         if self._gloo and parts.is_cuda:

@@ -230,3 +230,18 @@ def test_frappe_shaped_10m_row_table_split_over_two_owners():
     for j in range(3):
         tot = res[0][3][j] + res[1][3][j]
         assert abs(tot - one[2][j]) <= 1e-9 * max(1.0, abs(one[2][j])), (j, tot, one[2][j])
+
+
+def test_rccl_collectives_of_a_step_with_one_rank():
+    """The RCCL calls themselves (gloo stands in for them in the two-process tests above, which share one GPU): one rank,
+    backend nccl, FMX_FORCE_COLLECTIVES=1 -- 20 steps through FieldOwnerFM (prefetch tokens) and DataParallelFM end
+    bit-identical to fmx_fm_stream (tools/nccl_world1_check.py, run as the driver launches bench.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(root, "tools", "nccl_world1_check.py")], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "field owners, nccl, 1 rank, forced collectives: 20 steps bit-identical" in r.stdout
+    assert "replicated mode, nccl, 1 rank, forced collectives: bit-identical" in r.stdout
