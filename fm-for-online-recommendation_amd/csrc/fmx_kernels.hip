@@ -2135,12 +2135,6 @@ struct Tune {
                               // software prefetch from the stage that runs ahead).  Measured SLOWER -- fresh 20-step run 39.4 vs
                               // 33.5 us/step, steady state 28.2 vs 24.0: the sort waits for its 8 extra loads per thread and the
                               // two streams then fight for the same lines -- so off
-  int table_prewarm = 0;      // FMX_TABLE_PREWARM=n / fmx_set_option("table_prewarm", n): fmx_fm_stream starts with one streaming read of the
-                              // table (n workgroups of 256 threads, on a third stream, joined at the end) when the call has >= 4 steps
-                              // and the table is <= 1 GiB: rows come from the Infinity Cache afterwards instead of HBM
-  int wgrad_reduce = 1;       // FMX_WGRAD_REDUCE=0 / fmx_set_option("wgrad_reduce", 0): the split-K partials of k_mlp_wgrad are summed by
-                              // a second launch (k_mlp_reduce) instead of by each tile's last-arriving workgroup; identical bits
-  int wgrad_wgs = 128;        // FMX_WGRAD_WGS: workgroups a layer's weight-gradient product is split into at most (tiles x batch splits)
   int mlp_chain = 1;          // FMX_MLP_CHAIN=0 / fmx_set_option("mlp_chain", 0): fmx_mlp_section as separate GEMM launches
                               // (forward x L, loss, dgrad x L) instead of k_mlp_chain; same results up to summation order
   int fused_debug = 0;        // FMX_FUSED_DEBUG (timing experiments, wrong results): 1 no forward workgroups, 2 forward does not wait
@@ -2165,9 +2159,6 @@ Tune &tune() {
     if (const char *e = getenv("FMX_FUSED_DEBUG")) x.fused_debug = atoi(e);
     if (const char *e = getenv("FMX_MLP_CHAIN")) x.mlp_chain = atoi(e);
     if (const char *e = getenv("FMX_SORT_PREFETCH")) x.sort_prefetch = atoi(e);
-    if (const char *e = getenv("FMX_WGRAD_REDUCE")) x.wgrad_reduce = atoi(e);
-    if (const char *e = getenv("FMX_WGRAD_WGS")) x.wgrad_wgs = atoi(e) > 0 ? atoi(e) : 128;
-    if (const char *e = getenv("FMX_TABLE_PREWARM")) x.table_prewarm = atoi(e);
     if (const char *e = getenv("FMX_FUSED_WPB")) x.fused_wpb = atoi(e) == 16 ? 16 : 4;
     if (const char *e = getenv("FMX_FUSED_FIRST_SLEEP")) x.fused_first_sleep = atoi(e);
     if (const char *e = getenv("FMX_FUSED_POLL_SLEEP")) x.fused_poll_sleep = atoi(e);
@@ -2232,9 +2223,6 @@ struct Side {
                                  // cannot be captured into a hipGraph
   hipEvent_t fork = nullptr, sorted[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
   hipEvent_t user_fork = nullptr, user_join = nullptr;
-  hipStream_t warm = nullptr;    // the table read at the start of fmx_fm_stream ("table_prewarm")
-  hipEvent_t warm_done = nullptr;
-  float *warm_sink = nullptr;
 };
 
 Side *side_for_current_device() {
@@ -2257,9 +2245,6 @@ Side *side_for_current_device() {
       ok = hipEventCreateWithFlags(&sd.sorted[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&sd.consumed[i], hipEventDisableTiming) == hipSuccess;
     }
-    ok = ok && hipStreamCreateWithPriority(&sd.warm, hipStreamNonBlocking, lo) == hipSuccess &&
-         hipEventCreateWithFlags(&sd.warm_done, hipEventDisableTiming) == hipSuccess &&
-         hipMalloc(&sd.warm_sink, 256) == hipSuccess;
     if (!ok) return nullptr;
   }
   return &sd;
@@ -2729,8 +2714,6 @@ int fmx_set_option(const char *name, int value) {
   else if (!strcmp(name, "fused_step")) slot = &t.fused_step;
   else if (!strcmp(name, "mlp_chain")) slot = &t.mlp_chain;
   else if (!strcmp(name, "sort_prefetch")) slot = &t.sort_prefetch;
-  else if (!strcmp(name, "wgrad_reduce")) slot = &t.wgrad_reduce;
-  else if (!strcmp(name, "table_prewarm")) slot = &t.table_prewarm;
   else return fail(FMX_ERR_ARG, "fmx_set_option: unknown option '%s'", name);
   const int old = *slot;
   *slot = value;
@@ -2948,20 +2931,11 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
       mb.sorted_stride = (int64_t)w.sorted_stride;
       return sort_impl(table, idx_pool, B, w.sorted + (size_t)(g & 1) * ahead * w.sorted_stride, w.runs, fwd->error, where, &mb);
     };
-    bool warming = false;
     if (sd && n_steps > 0) {
       (void)hipEventRecord(sd->fork, st);
       (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
       rc = sort_group(0, 0, group_size(0, 0), sd->stream);
       (void)hipEventRecord(sd->sorted[0], sd->stream);
-      const int64_t table_bytes = (int64_t)table->n_rows * table->row_stride * (int64_t)sizeof(float);
-      if (tune().table_prewarm > 0 && n_steps >= 4 && table_bytes <= ((int64_t)1 << 30) && table_bytes % 16 == 0) {
-        (void)hipStreamWaitEvent(sd->warm, sd->fork, 0);
-        hipLaunchKernelGGL(k_stream_read, dim3(tune().table_prewarm), dim3(256), 0, sd->warm,
-                           static_cast<const float4 *>(static_cast<const void *>(table->rows)), table_bytes / 16, sd->warm_sink);
-        (void)hipEventRecord(sd->warm_done, sd->warm);
-        warming = true;
-      }
     }
     int first_step = 0;
     for (int g = 0; first_step < n_steps && rc == FMX_OK; ++g) {
@@ -3012,7 +2986,6 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
       if (sd) (void)hipEventRecord(sd->consumed[g & 1], st);
       first_step = next_first;
     }
-    if (warming) (void)hipStreamWaitEvent(st, sd->warm_done, 0);
     return rejoin(rc);
   }
 
@@ -3326,7 +3299,6 @@ static void mlp_big_forward(const fmx_mlp_t *mlp, const MlpBigWs &w, const float
   for (int l = 0; l < L; ++l) {
     const int in = l == 0 ? k : H;
     GemmArgs g;
-    g.stamps = nullptr;
     g.mask = nullptr;
     g.rowadd = nullptr;
     g.ldmask = 0;
@@ -3387,7 +3359,7 @@ int64_t fmx_mlp_section_workspace_bytes(const fmx_mlp_t *mlp, int32_t B) {
 // skip_dgrad: k_mlp_chain has already produced every dH_l and gbi; only the weight gradients and their reduction remain
 static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const float *bi, int32_t ld_bi, int32_t B,
                              const float *rowadd_l, float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply,
-                             float *loss_out, float inv_b, hipStream_t st, bool skip_dgrad = false, bool tickets_zeroed = false) {
+                             float *loss_out, float inv_b, hipStream_t st, bool skip_dgrad = false) {
   const int L = mlp->n_layers, H = mlp->hidden, k = mlp->k;
   const size_t act = align_up((size_t)B * H * 4, 256) / 4;
   const float *Wl[MLP_BIG_MAX_L];
@@ -3409,15 +3381,12 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
     g.ldmask = 0;
     g.c_split_stride = 0;
     g.zero_cols_to = 0;
-    g.stamps = nullptr;
     return g;
   };
   int splits[MLP_BIG_MAX_L] = {0};
   WgradBatch wb;
   wb.n = 0;
-  const bool in_launch = tune().wgrad_reduce != 0;
-  if (in_launch && !tickets_zeroed) (void)hipMemsetAsync(w.tickets, 0, w.ticket_bytes, st);
-  int wgx = 1, next_ticket = 0;
+  int wgx = 1;
   for (int l = L - 1; l >= 0; --l) {
     const int in = l == 0 ? k : H;
     float *cur = w.dH + (size_t)l * act;
@@ -3436,7 +3405,7 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
       g.K = B;
       // as many splits of the batch as keep a layer's grid within two workgroups per CU (70 KB of LDS each), at most B / 256
       const int tiles = ((in + G_BN - 1) / G_BN) * ((H + G_BM - 1) / G_BM);
-      int n_split = tune().wgrad_wgs / tiles;
+      int n_split = 512 / tiles;
       if (n_split > w.n_split) n_split = w.n_split;
       if (n_split < 1) n_split = 1;
       g.k_chunk = ((B + n_split - 1) / n_split + G_BK_WGRAD - 1) / G_BK_WGRAD * G_BK_WGRAD;
@@ -3446,14 +3415,9 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
       g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
       g.b_bytes = (unsigned)((size_t)B * g.ldb * 4);
       g.vec = (size_t)B * (g.lda > g.ldb ? g.lda : g.ldb) * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 1, 0);
-      if (tune().wgrad_reduce == 2) g.stamps = reinterpret_cast<unsigned long long *>(w.dzl);  // debug: tools/wgrad_stamps.py (dzl + loss_lb: Hedge only)
       wb.g[wb.n] = g;                                  // launched together with the other layers' after the dgrad chain
       wb.z_end[wb.n] = (wb.n ? wb.z_end[wb.n - 1] : 0) + n_split;
       wb.bias_col[wb.n] = in;
-      wb.ticket_base[wb.n] = next_ticket;
-      next_ticket += ((H + G_BM - 1) / G_BM) * ((in + G_BN - 1) / G_BN + 1);
-      wb.n_split[wb.n] = n_split;
-      wb.grad_off[wb.n] = off[l];
       if ((in + G_BN - 1) / G_BN > wgx) wgx = (in + G_BN - 1) / G_BN;
       ++wb.n;
     }
@@ -3492,22 +3456,10 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
                                 (int)g_lds_bytes(G_BK_WGRAD));
       raised = true;
     }
-    wb.tickets = in_launch ? w.tickets : nullptr;
-    wb.grads = grads;
-    wb.params = mlp->params;
-    wb.lr = lr_apply;
-    wb.loss_b = w.loss_b;
-    wb.loss_out = loss_out;
-    wb.B = B;
-    wb.inv_b = inv_b;
-    // logical grid: x = the GEMM's column tiles + one slice for the bias columns (y there = blocks of 64 columns of dH_l),
-    // y = row tiles, z = the layers' batch splits; dealt to the XCDs by split (k_mlp_wgrad)
-    wb.gx = wgx + 1;
-    wb.gy = (H + G_BM - 1) / G_BM;
-    wb.gz = wb.z_end[wb.n - 1];
-    hipLaunchKernelGGL(k_mlp_wgrad, dim3(8 * wb.gx * wb.gy * ((wb.gz + 7) / 8)), dim3(WGRAD_NT), g_lds_bytes(G_BK_WGRAD), st, wb);
+    // grid x = the GEMM's column tiles + one slice for the bias columns (y there = blocks of 64 columns of dH_l)
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3(wgx + 1, (H + G_BM - 1) / G_BM, wb.z_end[wb.n - 1]), dim3(256), g_lds_bytes(G_BK_WGRAD), st,
+                       wb);
   }
-  if (in_launch) return;
   MlpReduceArgs a;
   long long biggest = 0;
   for (int l = 0; l < MLP_BIG_MAX_L; ++l) {
@@ -3580,8 +3532,6 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     c.ld_gbi = ld_gbi;
     c.loss_kind = loss_kind;
     c.inv_b = inv_b;
-    c.tickets = tune().wgrad_reduce ? w.tickets : nullptr;
-    c.n_tickets = (int)(w.ticket_bytes / 4);
     c.stamps = tune().mlp_chain == 2 ? reinterpret_cast<unsigned long long *>(w.loss_lb) : nullptr;  // debug: tools/mlp_chain_stamps.py
     static bool raised = false;
     if (!raised) {
@@ -3590,7 +3540,7 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
       raised = true;
     }
     hipLaunchKernelGGL(k_mlp_chain, dim3((B + CH_R - 1) / CH_R), dim3(512), chain_lds_bytes(H), st, c);
-    mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st, true, true);
+    mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st, true);
     return check_launch("fmx_mlp_section (k_mlp_chain)");
   }
   mlp_big_forward(mlp, w, bi, ld_bi, B, st);

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfmx.so")
+LIB_PATH = os.environ.get("FMX_LIB_PATH") or os.path.join(_HERE, "libfmx.so")  # FMX_LIB_PATH: another build of the same ABI (A/B timing)
 
 # enums of include/fmx.h
 OK, ERR_ARG, ERR_SHAPE, ERR_ALIGN, ERR_LAUNCH, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5

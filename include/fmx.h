@@ -142,11 +142,7 @@ const char *fmx_last_error_string(void);
  *                                agent-scope acquire per forward workgroup and plain gather loads, 2: sc1 gather loads).
  *   "mlp_chain"    (default 1)  0: fmx_mlp_section as separate GEMM launches instead of k_mlp_chain (forward + loss + dgrad chain
  *                                in one launch); same results up to summation order.
- *   "wgrad_reduce" (default 1)  1: the batch-split partials of the MLP's weight-gradient launch are summed by each tile's
- *                                last-arriving workgroup (inside k_mlp_wgrad); 0: by a second launch (k_mlp_reduce).
  *   "sort_prefetch" (default 0) 1: the occurrence sort also touches the rows of its batch (measured slower).
- *   "table_prewarm" (default 0) n > 0: fmx_fm_stream starts with one streaming read of the table by n workgroups on a third
- *                                stream (measured: no gain).
  *   "online_persistent" (default 1)  0: fmx_online_run_mlp as per-sample launches instead of one workgroup walking the stream. */
 int fmx_set_option(const char *name, int value);
 

@@ -154,42 +154,3 @@ def test_mlp_hedge_section_vs_autograd(fmx, B, k, kp, H, L):
     close((params - p0).cpu().numpy(), new - p.numpy(), "parameter deltas", rel=5e-5)
     np.testing.assert_array_equal((p0 - lr * grads).cpu().numpy(), params.cpu().numpy())
 
-
-@pytest.mark.parametrize("B,k,kp,H,L,loss", CASES)
-def test_wgrad_in_launch_reduction_equals_reduce_launch(fmx, B, k, kp, H, L, loss):
-    """The split-K partials of k_mlp_wgrad summed by each tile's last-arriving workgroup (the default) or by the second
-    launch k_mlp_reduce (fmx_set_option("wgrad_reduce", 0)): the same order over the splits, so identical bits -- flat
-    gradients, the SGD-updated parameters and the loss -- also on a workspace full of garbage and on repeated calls."""
-    import ctypes as C
-    torch.manual_seed(7 * B + H)
-    n_par = sum(H * (k if l == 0 else H) + H for l in range(L))
-    p_init = (torch.randn(n_par) * (1.0 / np.sqrt(H))).cuda()
-    bi_d = torch.zeros(B, kp, device="cuda")
-    bi_d[:, :k] = torch.randn(B, k, device="cuda") * 0.5
-    base = (torch.randn(B) * 0.3).cuda()
-    y = (torch.rand(B) < 0.3).float().cuda()
-    lib = fmx._lib.load()
-    res = {}
-    for mode in (1, 0):
-        old = lib.fmx_set_option(b"wgrad_reduce", mode)
-        try:
-            params = p_init.clone()
-            m = fmx._lib.Mlp(params.data_ptr(), L, k, H, 0)
-            ws = torch.full((int(lib.fmx_mlp_section_workspace_bytes(C.byref(m), B)) // 4,), float("nan"), device="cuda")
-            ws.view(torch.int32)[-4096:] = 0x7FFFFFF0  # garbage where the tickets live
-            dz, gbi = torch.empty(B, device="cuda"), torch.empty(B, kp, device="cuda")
-            grads, loss_out = torch.zeros_like(params), torch.zeros(1, device="cuda")
-            outs = []
-            for rep in range(3):  # three SGD steps: the tickets are reset every launch
-                fmx._lib.check(lib.fmx_mlp_section(C.byref(m), fmx._lib.LOSSES[loss], bi_d.data_ptr(), kp, base.data_ptr(), y.data_ptr(),
-                                                   B, 1.0 / B, ws.data_ptr(), None, dz.data_ptr(), gbi.data_ptr(), kp, grads.data_ptr(),
-                                                   0.05, loss_out.data_ptr(), torch.cuda.current_stream().cuda_stream))
-                torch.cuda.synchronize()
-                outs.append((grads.clone(), params.clone(), loss_out.clone()))
-            res[mode] = outs
-        finally:
-            lib.fmx_set_option(b"wgrad_reduce", old)
-    for a, b in zip(res[1], res[0]):
-        for x, y_, what in zip(a, b, ("flat gradients", "parameters", "loss")):
-            assert torch.isfinite(x).all(), what
-            assert torch.equal(x, y_), what

@@ -29,5 +29,5 @@ for chain in (1, 0):
     lib.fmx_set_option(b"mlp_chain", old)
     us = e0.elapsed_time(e1) / 200 * 1e3
     flop = 6 * B * (k * H + (L - 1) * H * H)
-    print(f"mlp_chain={chain}: {us:.1f} us per fmx_mlp_section call (3 x 256, B = 4096; {2 if chain else 8} launches) = "
+    print(f"mlp_chain={chain}: {us:.1f} us per fmx_mlp_section call (3 x 256, B = 4096; {3 if chain else 10} launches) = "
           f"{flop / us / 1e6:.1f} TFLOP/s = {flop / us / 1e6 / 157.3:.3f} of the fp32 MFMA peak", flush=True)
