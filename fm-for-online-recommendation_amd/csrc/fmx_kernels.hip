@@ -570,6 +570,8 @@ __device__ __forceinline__ void forward_sample(const FwdArgs &a, const int b, co
   const float y_early = a.loss_kind != FMX_LOSS_NONE ? a.y[b] : 0.f;
   const float bias0_early = a.bias[0];
   const float bias1_early = LAYOUT == FMX_LAYOUT_WEIGHTS ? 0.f : a.bias[1];
+  __builtin_amdgcn_sched_barrier(0);  // (left to itself the scheduler sinks the bias load behind the first waits of the gather:
+                                      //  in-order vmcnt then makes the row requests wait for it -- one more round trip)
   const int n_outer = NPASS > 0 ? 1 : (a.F + SLOTS - 1) / SLOTS;
   for (int it = 0; it < n_outer; ++it) {
     uint32_t li[NP];
@@ -577,50 +579,60 @@ __device__ __forceinline__ void forward_sample(const FwdArgs &a, const int b, co
     int64_t lo[NP];
     uint32_t vocab[NP];
     bool live[NP];
+    // Branch-free: a lane group beyond the last field reads field F - 1's index and offsets, an index beyond the field's
+    // vocabulary reads the field's first row, and the results are dropped by selects.  With `if (live) { loads; arithmetic on
+    // them }` per pass the compiler put an s_waitcnt vmcnt(0) at the end of every pass's region: three dependent round trips
+    // for the indices of a 39-field sample instead of one.
+    const float *xsrc = a.xv ? a.xv : reinterpret_cast<const float *>(a.idx);  // something loadable when there are no values
+    const bool has_x = a.xv != nullptr;
+    float xl[NP];
+    int64_t hi[NP];
+    int fc[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int f = (it * NP + p) * SLOTS + slot;
       live[p] = f < a.F;
-      li[p] = 0;
-      x[p] = 1.f;
-      lo[p] = 0;
-      vocab[p] = 0;
-      if (live[p]) {
-        const size_t o = (size_t)b * a.F + f;
-        li[p] = (uint32_t)a.idx[o];
-        if (a.xv) x[p] = a.xv[o];
-        lo[p] = a.foff[f];
-        vocab[p] = (uint32_t)(a.foff[f + 1] - lo[p]);
-      }
+      fc[p] = live[p] ? f : a.F - 1;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {  // the offsets do not depend on the sample: first
+      lo[p] = a.foff[fc[p]];
+      hi[p] = a.foff[fc[p] + 1];
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const size_t o = (size_t)b * a.F + fc[p];
+      li[p] = (uint32_t)a.idx[o];
+      xl[p] = xsrc[o];
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      x[p] = has_x ? xl[p] : 1.f;
+      vocab[p] = (uint32_t)(hi[p] - lo[p]);
     }
     // both layouts keep [ V | w ] at the head of the row: the forward never touches the FTRL (z, n) half
     float4 r0[NP];
     float rw[NP];
+    bool ok[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      r0[p] = splat(0.f);
-      rw[p] = 0.f;
-      if (live[p] && li[p] < vocab[p]) {
-        const float *rp = a.rows + (size_t)(lo[p] + li[p]) * a.stride;
-        r0[p] = *reinterpret_cast<const float4 *>(rp + 4 * q);
-        if (q == 0) rw[p] = rp[kp];
-      }
+      ok[p] = live[p] && li[p] < vocab[p];
+      const float *rp = a.rows + (size_t)(lo[p] + (ok[p] ? li[p] : 0u)) * a.stride;
+      r0[p] = *reinterpret_cast<const float4 *>(rp + 4 * q);
+      rw[p] = rp[kp];  // (every lane of the group: the same address, one request)
     }
+    __builtin_amdgcn_sched_barrier(0);  // ... and every row request before the first sum
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      if (live[p]) {
-        float f1 = 0.f;
-        if (li[p] < vocab[p]) {
-          const float4 e = x[p] * r0[p];
-          s = s + e;
-          ss = ss + e * e;
-          f1 = rw[p] * x[p];
-          fo += f1;
-        } else {
-          bad = true;
-        }
-        if (a.out.first && q == 0) a.out.first[(size_t)b * a.F + (it * NP + p) * SLOTS + slot] = f1;
+      const float4 e = x[p] * r0[p];
+      const float f1 = ok[p] ? rw[p] * x[p] : 0.f;
+      if (ok[p]) {  // selects
+        s = s + e;
+        ss = ss + e * e;
+        fo += f1;
       }
+      bad = bad || (live[p] && !ok[p]);
+      if (live[p] && a.out.first && q == 0) a.out.first[(size_t)b * a.F + (it * NP + p) * SLOTS + slot] = f1;
     }
   }
   forward_finish<LPR, LAYOUT>(a, b, lane, s, ss, fo, bad, y_early, bias0_early, bias1_early);
@@ -666,53 +678,59 @@ __global__ __launch_bounds__(256) void k_fm_forward_part(PartArgs a) {
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int b = wave * (SLOTS >> a.sl_log2) + (slot >> a.sl_log2);
   const bool valid = b < a.B;
+  // branch-free gather, as in forward_sample: every offset and index load, then every row load, then the sums by selects
   uint32_t li[NPASS], vocab[NPASS];
-  float x[NPASS];
-  int64_t lo[NPASS];
-  bool live[NPASS];
+  float x[NPASS], xl[NPASS];
+  int64_t lo[NPASS], hi[NPASS];
+  bool live[NPASS], ok[NPASS];
+  int fc[NPASS];
+  const float *xsrc = a.xv ? a.xv : reinterpret_cast<const float *>(a.idx);
+  const bool has_x = a.xv != nullptr;
+  const int bc = valid ? b : 0;
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
     const int f = p * SL + slot_l;
     live[p] = valid && f < a.F;
-    li[p] = 0;
-    x[p] = 1.f;
-    lo[p] = 0;
-    vocab[p] = 0;
-    if (live[p]) {
-      const size_t o = (size_t)b * a.F + f;
-      li[p] = (uint32_t)a.idx[o];
-      if (a.xv) x[p] = a.xv[o];
-      lo[p] = a.foff[f];
-      vocab[p] = (uint32_t)(a.foff[f + 1] - lo[p]);
-    }
+    fc[p] = f < a.F ? f : a.F - 1;
+  }
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    lo[p] = a.foff[fc[p]];
+    hi[p] = a.foff[fc[p] + 1];
+  }
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const size_t o = (size_t)bc * a.F + fc[p];
+    li[p] = (uint32_t)a.idx[o];
+    xl[p] = xsrc[o];
+  }
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    x[p] = has_x ? xl[p] : 1.f;
+    vocab[p] = (uint32_t)(hi[p] - lo[p]);
   }
   float4 r0[NPASS];
   float rw[NPASS];
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
-    r0[p] = splat(0.f);
-    rw[p] = 0.f;
-    if (live[p] && li[p] < vocab[p]) {
-      const float *rp = a.rows + (size_t)(lo[p] + li[p]) * a.stride;
-      r0[p] = *reinterpret_cast<const float4 *>(rp + 4 * q);
-      if (q == 0) rw[p] = rp[kp];
-    }
+    ok[p] = live[p] && li[p] < vocab[p];
+    const float *rp = a.rows + (size_t)(lo[p] + (ok[p] ? li[p] : 0u)) * a.stride;
+    r0[p] = *reinterpret_cast<const float4 *>(rp + 4 * q);
+    rw[p] = rp[kp];
   }
+  __builtin_amdgcn_sched_barrier(0);
   float4 s = splat(0.f), ss = splat(0.f);
   float fo = 0.f;
   bool bad = false;
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
-    if (live[p]) {
-      if (li[p] < vocab[p]) {
-        const float4 e = x[p] * r0[p];
-        s = s + e;
-        ss = ss + e * e;
-        fo += rw[p] * x[p];
-      } else {
-        bad = true;
-      }
+    const float4 e = x[p] * r0[p];
+    if (ok[p]) {  // selects
+      s = s + e;
+      ss = ss + e * e;
+      fo += rw[p] * x[p];
     }
+    bad = bad || (live[p] && !ok[p]);
   }
   if (bad && a.error) *a.error = 1;
   // the butterfly levels inside the owner's lane groups (wave-uniform conditions)
