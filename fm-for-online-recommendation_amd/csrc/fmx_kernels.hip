@@ -1099,16 +1099,16 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   for (int j = 0; j < EPG; ++j) tail[j] = val[j] && (k[j] != (j + 1 < EPG ? k[j + 1] : knext));
 
   // ---- issue the loads: rows of the runs that end here (HBM / MALL), then S of every occurrence (L2) ----
+  // Branch-free: an occurrence that is not the tail of a run starting in this tile requests the field's FIRST row instead
+  // (one address for all such lanes: one request per instruction) and never looks at the result.  With
+  // `if (tail) row[j] = load_row(...)` the compiler closed every j's region with s_waitcnt vmcnt(0): the four row requests
+  // of a lane group -- HBM / Infinity Cache round trips -- went out one after the other.
   RowRegs row[PREFETCH_ROWS ? EPG : 1];
   if (PREFETCH_ROWS) {
 #pragma unroll
     for (int j = 0; j < EPG; ++j) {
-      row[j].v = splat(0.f);
-      row[j].z = splat(0.f);
-      row[j].n = splat(0.f);
-      row[j].fo = splat(0.f);
-      if (tail[j] && k[j] != tile_prevkey)
-        row[j] = load_row<LAYOUT>(a.rows + (row0 + k[j]) * (size_t)a.stride, q, kp, a.zoff);
+      const bool need = tail[j] && k[j] != tile_prevkey;
+      row[j] = load_row<LAYOUT>(a.rows + (row0 + (need ? k[j] : 0u)) * (size_t)a.stride, q, kp, a.zoff);
     }
   }
   // INL: the row of the run that comes in from the previous tile (updated by THIS wave if the run ends here, by nobody
@@ -1116,32 +1116,54 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   RowRegs row_in;
   row_in.v = row_in.z = row_in.n = row_in.fo = splat(0.f);
   const bool run_comes_in = INL && base > 0 && val[0] && k[0] == tile_prevkey;  // meaningful in lane group 0
-  if (INL && slot == 0 && run_comes_in)
-    row_in = load_row<LAYOUT>(a.rows + (row0 + tile_prevkey) * (size_t)a.stride, q, kp, a.zoff);
+  if (INL)  // (branch-free like the rows above; used by lane group 0 of a closing tile only)
+    row_in = load_row<LAYOUT>(a.rows + (row0 + ((slot == 0 && run_comes_in) ? tile_prevkey : 0u)) * (size_t)a.stride, q, kp, a.zoff);
+  // Branch-free like the rows: a padding entry reads sample 0 and its contribution is dropped by a select.  (`if (val[j])
+  // { loads; products }` closed every j's region with s_waitcnt vmcnt(0): four dependent L2 round trips per lane group.)
   float4 cV[EPG];
   CA cA[EPG];
   float cw[EPG];
+  {
+    const bool has_x = a.xv != nullptr;
+    const float *xsrc = has_x ? a.xv : a.dz_first;  // something loadable
+    const int col = (has_x && a.cols) ? a.cols[f] : f;
+    const float *bisrc = a.dz_bi ? a.dz_bi : a.dz_first;
+    float4 S4[EPG], G4[EPG];
+    float xl[EPG], dzf[EPG], dzbl[EPG];
 #pragma unroll
-  for (int j = 0; j < EPG; ++j) {
-    cV[j] = splat(0.f);
-    cA[j].zero();
-    cw[j] = 0.f;
-    if (val[j]) {
-      const uint32_t b = c[j] & bmask;
-      const float4 S4 = *reinterpret_cast<const float4 *>(a.S + (size_t)b * a.ldS + 4 * q);
-      const float x = a.xv ? a.xv[(size_t)b * a.Fx + (a.cols ? a.cols[f] : f)] : 1.f;
-      const float dzf = a.dz_first[(size_t)b * a.ld1];
-      const float dzb = a.dz_bi == a.dz_first ? dzf : (a.dz_bi ? a.dz_bi[(size_t)b * a.ld1] : 0.f);
-      cw[j] = x * dzf;
+    for (int j = 0; j < EPG; ++j) {
+      const uint32_t b = val[j] ? (c[j] & bmask) : 0u;
+      S4[j] = *reinterpret_cast<const float4 *>(a.S + (size_t)b * a.ldS + 4 * q);
+      xl[j] = xsrc[has_x ? (size_t)b * a.Fx + col : (size_t)0];
+      dzf[j] = a.dz_first[(size_t)b * a.ld1];
+      dzbl[j] = bisrc[(size_t)b * a.ld1];
+      if constexpr (HAS_GBI) G4[j] = *reinterpret_cast<const float4 *>(a.gbi + (size_t)b * kp + 4 * q);
+      else G4[j] = splat(0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < EPG; ++j) {
+      const float x = has_x ? xl[j] : 1.f;
+      const float dzb = a.dz_bi ? dzbl[j] : 0.f;
+      const float w1 = x * dzf[j];
+      float4 v;
+      CA ca;
       if constexpr (HAS_GBI) {
-        const float4 G = splat(dzb) + *reinterpret_cast<const float4 *>(a.gbi + (size_t)b * kp + 4 * q);
+        const float4 G = splat(dzb) + G4[j];
         const float4 xG = x * G;
-        cV[j] = xG * S4;
-        cA[j].v = x * xG;
+        v = xG * S4[j];
+        ca.v = x * xG;
       } else {
         const float xG = x * dzb;
-        cV[j] = xG * S4;
-        cA[j].v = x * xG;
+        v = xG * S4[j];
+        ca.v = x * xG;
+      }
+      cV[j] = splat(0.f);
+      cA[j].zero();
+      cw[j] = 0.f;
+      if (val[j]) {  // selects
+        cV[j] = v;
+        cA[j] = ca;
+        cw[j] = w1;
       }
     }
   }
