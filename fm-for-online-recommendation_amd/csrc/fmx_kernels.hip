@@ -880,12 +880,15 @@ __device__ float block_sum(const float *src, int n, int ld, float *sm) {
     for (int i0 = tid; i0 < n4; i0 += U * nt) {
       float4 v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = i0 + u * nt;
-        v[u] = i < n4 ? src4[i] : float4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < U; ++u) {  // branch-free: a group beyond the end reads group 0 and counts as zeros (a branch per
+        const int i = i0 + u * nt;   // load made the compiler wait for every load before it issued the next)
+        v[u] = src4[i < n4 ? i : 0];
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+      for (int u = 0; u < U; ++u) {
+        const bool in = i0 + u * nt < n4;
+        acc += in ? (v[u].x + v[u].y) + (v[u].z + v[u].w) : 0.f;
+      }
     }
     for (int i = (n4 << 2) + tid; i < n; i += nt) acc += src[i];
   } else {  // strided sample records: the SAME order of additions as the dense form (groups of four elements, then the
@@ -897,14 +900,14 @@ __device__ float block_sum(const float *src, int n, int ld, float *sm) {
 #pragma unroll
       for (int u = 0; u < V; ++u) {
         const int i = i0 + u * nt;
-        v[u] = float4{0.f, 0.f, 0.f, 0.f};
-        if (i < n4) {
-          const float *p = src + (size_t)(4 * i) * ld;
-          v[u] = float4{p[0], p[ld], p[2 * (size_t)ld], p[3 * (size_t)ld]};
-        }
+        const float *p = src + (size_t)(4 * (i < n4 ? i : 0)) * ld;
+        v[u] = float4{p[0], p[ld], p[2 * (size_t)ld], p[3 * (size_t)ld]};
       }
 #pragma unroll
-      for (int u = 0; u < V; ++u) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+      for (int u = 0; u < V; ++u) {
+        const bool in = i0 + u * nt < n4;
+        acc += in ? (v[u].x + v[u].y) + (v[u].z + v[u].w) : 0.f;
+      }
     }
     for (int i = (n4 << 2) + tid; i < n; i += nt) acc += src[(size_t)i * ld];
   }
