@@ -980,12 +980,14 @@ __device__ __forceinline__ RowRegs load_row(const float *rp, int q, int kp, int 
   r.z = splat(0.f);
   r.n = splat(0.f);
   r.fo = splat(0.f);
+  // the first-order part is used by lane 0 of the group only, but every lane requests it (same address: one request): a
+  // load under `if (q == 0)` is a branch, and the compiler's wait counts fall back to vmcnt(0) around it
   if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
-    if (q == 0) r.fo.x = rp[kp];
+    r.fo.x = rp[kp];
   } else {
     r.z = *reinterpret_cast<const float4 *>(rp + zoff + 4 * q);
     r.n = *reinterpret_cast<const float4 *>(rp + zoff + kp + 4 * q);
-    if (q == 0) r.fo = *reinterpret_cast<const float4 *>(rp + kp);
+    r.fo = *reinterpret_cast<const float4 *>(rp + kp);
   }
   return r;
 }
@@ -1107,20 +1109,26 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   // `if (tail) row[j] = load_row(...)` the compiler closed every j's region with s_waitcnt vmcnt(0): the four row requests
   // of a lane group -- HBM / Infinity Cache round trips -- went out one after the other.
   RowRegs row[PREFETCH_ROWS ? EPG : 1];
-  if (PREFETCH_ROWS) {
-#pragma unroll
-    for (int j = 0; j < EPG; ++j) {
-      const bool need = tail[j] && k[j] != tile_prevkey;
-      row[j] = load_row<LAYOUT>(a.rows + (row0 + (need ? k[j] : 0u)) * (size_t)a.stride, q, kp, a.zoff);
-    }
-  }
   // INL: the row of the run that comes in from the previous tile (updated by THIS wave if the run ends here, by nobody
-  // else in this launch) is requested now, with the other rows, instead of behind this wave's own stores
+  // else in this launch) is requested with the other rows, instead of behind this wave's own stores
   RowRegs row_in;
   row_in.v = row_in.z = row_in.n = row_in.fo = splat(0.f);
   const bool run_comes_in = INL && base > 0 && val[0] && k[0] == tile_prevkey;  // meaningful in lane group 0
-  if (INL)  // (branch-free like the rows above; used by lane group 0 of a closing tile only)
-    row_in = load_row<LAYOUT>(a.rows + (row0 + ((slot == 0 && run_comes_in) ? tile_prevkey : 0u)) * (size_t)a.stride, q, kp, a.zoff);
+  auto request_rows = [&]() {
+    if (PREFETCH_ROWS) {
+#pragma unroll
+      for (int j = 0; j < EPG; ++j) {
+        const bool need = tail[j] && k[j] != tile_prevkey;
+        row[j] = load_row<LAYOUT>(a.rows + (row0 + (need ? k[j] : 0u)) * (size_t)a.stride, q, kp, a.zoff);
+      }
+    }
+    if (INL)  // (branch-free like the rows above; used by lane group 0 of a closing tile only)
+      row_in = load_row<LAYOUT>(a.rows + (row0 + ((slot == 0 && run_comes_in) ? tile_prevkey : 0u)) * (size_t)a.stride, q, kp, a.zoff);
+  };
+  // A tile whose last run goes on into the next tile PUBLISHES its partial sums (below) for the tile that closes the run,
+  // and the publication waits for everything this wave has in flight (s_waitcnt vmcnt(0) before the flag): such a tile
+  // requests its rows only AFTER it has published -- its sums need S and dlogit (L2), not the rows (HBM / Infinity Cache).
+  const bool tile_open_early = INL && __shfl((int)(val[EPG - 1] && k[EPG - 1] == knext), WAVE - 1) != 0;  // wave-uniform
   // Branch-free like the rows: a padding entry reads sample 0 and its contribution is dropped by a select.  (`if (val[j])
   // { loads; products }` closed every j's region with s_waitcnt vmcnt(0): four dependent L2 round trips per lane group.)
   float4 cV[EPG];
@@ -1143,6 +1151,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
       if constexpr (HAS_GBI) G4[j] = *reinterpret_cast<const float4 *>(a.gbi + (size_t)b * kp + 4 * q);
       else G4[j] = splat(0.f);
     }
+    if (!tile_open_early) request_rows();
 #pragma unroll
     for (int j = 0; j < EPG; ++j) {
       const float x = has_x ? xl[j] : 1.f;
@@ -1254,6 +1263,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
     a.meta[(size_t)gt * 2 + 1] = trail_state;
   }
 
+  if (tile_open_early) request_rows();
   // ---- pass 2: walk the occurrences again; at the tail of a run apply the update or leave a partial ----
   float4 leadV = splat(0.f), leadA = splat(0.f);  // INL: this tile's part of the run that came in and ends here
   float leadw = 0.f;
