@@ -1551,12 +1551,12 @@ __device__ __forceinline__ RowRegs load_row_sc1(const float *rp, int q, int kp, 
   r.z = splat(0.f);
   r.n = splat(0.f);
   r.fo = splat(0.f);
-  if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
-    if (q == 0) r.fo.x = ld_sc1(rp + kp);
+  if (LAYOUT == FMX_LAYOUT_WEIGHTS) {  // (every lane, as in load_row: no branch around a load)
+    r.fo.x = ld_sc1(rp + kp);
   } else {
     r.z = ld_sc1_4(rp + zoff + 4 * q);
     r.n = ld_sc1_4(rp + zoff + kp + 4 * q);
-    if (q == 0) r.fo = ld_sc1_4(rp + kp);
+    r.fo = ld_sc1_4(rp + kp);
   }
   return r;
 }
@@ -1580,18 +1580,26 @@ __global__ __launch_bounds__(64) void k_fm_online(OnlineArgs a) {
   }
   uint32_t li_n[NP];
   float x_n[NP], y_n = 0.f;
+  // branch-free (see forward_sample): beyond the stream or the last field the loads read element 0 and are dropped
+  const float *xsrc = a.xv ? a.xv : reinterpret_cast<const float *>(a.idx);
+  const bool has_x = a.xv != nullptr;
   auto fetch_inputs = [&](int i) {
+    const bool in = i < a.N;
+    uint32_t l_[NP];
+    float x_[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      li_n[p] = 0;
-      x_n[p] = 1.f;
-      if (live[p] && i < a.N) {
-        const size_t o = (size_t)i * a.F + p * SLOTS + slot;
-        li_n[p] = (uint32_t)a.idx[o];
-        if (a.xv) x_n[p] = a.xv[o];
-      }
+      const size_t o = (live[p] && in) ? (size_t)i * a.F + p * SLOTS + slot : (size_t)0;
+      l_[p] = (uint32_t)a.idx[o];
+      x_[p] = xsrc[o];
     }
-    y_n = i < a.N ? a.y[i] : 0.f;
+    const float yy = a.y[in ? i : 0];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      li_n[p] = (live[p] && in) ? l_[p] : 0u;
+      x_n[p] = (has_x && live[p] && in) ? x_[p] : 1.f;
+    }
+    y_n = in ? yy : 0.f;
   };
   fetch_inputs(0);
   bool bad = false;
@@ -1609,12 +1617,10 @@ __global__ __launch_bounds__(64) void k_fm_online(OnlineArgs a) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       ok[p] = live[p] && li[p] < vocab[p];
-      row[p].v = splat(0.f);
-      row[p].z = splat(0.f);
-      row[p].n = splat(0.f);
-      row[p].fo = splat(0.f);
-      if (ok[p]) row[p] = load_row_sc1<LAYOUT>(a.rows + (size_t)(lo[p] + li[p]) * a.stride, q, kp, a.zoff);
-      else if (live[p]) bad = true;
+      // branch-free: a dead lane group or a bad index requests the table's first row and drops it (with a branch per
+      // pass the rows of a sample went out in NP dependent round trips)
+      row[p] = load_row_sc1<LAYOUT>(a.rows + (size_t)(ok[p] ? lo[p] + li[p] : 0) * a.stride, q, kp, a.zoff);
+      bad = bad || (live[p] && !ok[p]);
     }
     fetch_inputs(i + 1);  // independent of the weights: in flight while this sample is processed
     // ---- forward: the arithmetic of k_fm_forward ----
