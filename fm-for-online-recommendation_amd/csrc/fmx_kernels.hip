@@ -3462,9 +3462,9 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
       g.M = H;
       g.N = in;
       g.K = B;
-      // as many splits of the batch as keep a layer's grid within two workgroups per CU (70 KB of LDS each), at most B / 256
+      // splits of the batch: 16 for a 256 x 256 layer (528 workgroups over the launch), at most B / 128
       const int tiles = ((in + G_BN - 1) / G_BN) * ((H + G_BM - 1) / G_BM);
-      int n_split = 512 / tiles;
+      int n_split = 256 / tiles;  // (192 .. 384: the same within 0.5 us; 128: +6 us, 512 / 1024: +4 us -- tools/mlp_section_times.py)
       if (n_split > w.n_split) n_split = w.n_split;
       if (n_split < 1) n_split = 1;
       g.k_chunk = ((B + n_split - 1) / n_split + G_BK_WGRAD - 1) / G_BK_WGRAD * G_BK_WGRAD;
