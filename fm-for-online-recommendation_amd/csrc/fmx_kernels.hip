@@ -1984,22 +1984,30 @@ __global__ __launch_bounds__(256) void k_online_mlp(OnlineMlpArgs a) {
     float4 S = splat(0.f);
     if (wave == 0) {
       // ---- the FM part: the arithmetic of k_fm_forward ----
+      // branch-free, all index loads before all row loads (see forward_sample / k_fm_online): with the loads of a pass under
+      // `if (live[p])` a sample's rows went out in 2 NP dependent round trips
+      {
+        const float *xsrc = a.xv ? a.xv : reinterpret_cast<const float *>(a.idx);
+        const bool has_x = a.xv != nullptr;
+        uint32_t l_[NP];
+        float x_[NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        li[p] = 0;
-        x[p] = 1.f;
-        if (live[p]) {
-          const size_t o = (size_t)i * a.F + p * SLOTS + slot;
-          li[p] = (uint32_t)a.idx[o];
-          if (a.xv) x[p] = a.xv[o];
+        for (int p = 0; p < NP; ++p) {
+          const size_t o = live[p] ? (size_t)i * a.F + p * SLOTS + slot : (size_t)0;
+          l_[p] = (uint32_t)a.idx[o];
+          x_[p] = xsrc[o];
         }
-        ok[p] = live[p] && li[p] < vocab[p];
-        row[p].v = splat(0.f);
-        row[p].z = splat(0.f);
-        row[p].n = splat(0.f);
-        row[p].fo = splat(0.f);
-        if (ok[p]) row[p] = load_row_sc1<LAYOUT>(a.rows + (size_t)(lo[p] + li[p]) * a.stride, q, kp, a.zoff);
-        else if (live[p]) bad = true;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          li[p] = live[p] ? l_[p] : 0u;
+          x[p] = (has_x && live[p]) ? x_[p] : 1.f;
+          ok[p] = live[p] && li[p] < vocab[p];
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          row[p] = load_row_sc1<LAYOUT>(a.rows + (size_t)(ok[p] ? lo[p] + li[p] : 0) * a.stride, q, kp, a.zoff);
+          bad = bad || (live[p] && !ok[p]);
+        }
       }
       float4 s = splat(0.f), ss = splat(0.f);
       float fo = 0.f;
