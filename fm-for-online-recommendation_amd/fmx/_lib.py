@@ -18,7 +18,7 @@ EXPORTS = ["fmx_version", "fmx_last_error_string", "fmx_set_option", "fmx_sorted
            "fmx_fm_forward", "fmx_mlp_forward", "fmx_mlp_fit", "fmx_mlp_hedge_fit", "fmx_mlp_section",
            "fmx_mlp_section_workspace_bytes", "fmx_fm_online_run", "fmx_online_run_mlp", "fmx_mlp_forward_batch", "fmx_mlp_hedge_section",
            "fmx_sort_occurrences", "fmx_fm_update", "fmx_fm_step", "fmx_fm_stream", "fmx_stream_read",
-           "fmx_fm_forward_partial", "fmx_fm_forward_finish", "fmx_sftrl_run"]
+           "fmx_fm_forward_partial", "fmx_fm_forward_finish", "fmx_sftrl_run", "fmx_sftrl_grid"]
 
 
 I64_RETURNS = ("fmx_workspace_bytes", "fmx_mlp_section_workspace_bytes")   # byte counts: int64_t in include/fmx.h
@@ -76,6 +76,7 @@ def load():
     lib.fmx_fm_forward.argtypes = [TP, HP, p, p, p, i32, i32, f32, FP, p]
     lib.fmx_sort_occurrences.argtypes = [TP, p, i32, p, p, p]
     lib.fmx_sftrl_run.argtypes = [p, p, i32, i32, i32, i32, C.c_double, C.c_double, i32, p, p, p, p, p, p, p, p]
+    lib.fmx_sftrl_grid.argtypes = [p, p, i32, i32, i32, i32, p, p, i32, C.c_double, i32, p, p, p, p, p, p, p, p]
     lib.fmx_fm_forward_partial.argtypes = [TP, p, p, i32, i32, p, p, p]
     lib.fmx_fm_forward_finish.argtypes = [HP, p, i32, i32, p, i64, i32, p, i32, i32, f32, FP, p]
     lib.fmx_fm_update.argtypes = [TP, HP, i32, p, p, p, p, p, p, i32, i32, p, f32, p, p]

@@ -122,5 +122,56 @@ class SFTRL_CCFM(FM_Base):
             print(" %d th : pred %f , real %f " % (idx, p[idx], y[idx]))
         return p.reshape((n,) + self._pred_shape(cls))
 
+    @classmethod
+    def grid(cls, inputs_matrix, outputs, task, learning_rates, num_features):
+        """An extension the reference lacks (its notebooks try one (learning_rate, m) pair per run): every pair of
+        `learning_rates` x `num_features` over the SAME stream in ONE launch (fmx_sftrl_grid: one wavefront per setting,
+        up to 256 settings side by side).  -> list of (model, predictions) in the order of itertools.product; every model
+        is what `cls(..., lr, m, device="gpu").online_learning()` leaves behind, bit for bit."""
+        import ctypes as C
+        import itertools
+
+        from fmx import _lib
+        if task not in ("cls", "reg"):
+            raise NotImplementedError
+        settings = list(itertools.product(learning_rates, num_features))
+        models = [cls(inputs_matrix, outputs, task, lr, m, device="gpu") for lr, m in settings]
+        if not settings:
+            return []
+        lib = _lib.load()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        m0 = models[0]
+        X = m0.At.t().contiguous().numpy().astype(np.float64, copy=False)
+        y = np.asarray(m0.b.reshape(-1).numpy(), dtype=np.float64)
+        n, D = X.shape
+        d, S, m_max = m0._sketch_dim(), len(settings), max(m for _, m in settings)
+        Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+        ms = torch.tensor([m for _, m in settings], dtype=torch.int32, device=dev)
+        etas = torch.tensor([float(lr) for lr, _ in settings], dtype=torch.float64, device=dev)
+        BP = torch.zeros((S, d * 2 * m_max), dtype=torch.float64, device=dev)
+        BN = torch.zeros_like(BP)
+        counts = torch.zeros((S, 2), dtype=torch.int32, device=dev)
+        w = g_w = None
+        if cls._linear_term:
+            w, g_w = torch.zeros((S, D), dtype=torch.float64, device=dev), torch.zeros((S, D), dtype=torch.float64, device=dev)
+        pred = torch.empty((S, n), dtype=torch.float64, device=dev)
+        status = torch.zeros((S, 2), dtype=torch.int32, device=dev)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _lib.check(lib.fmx_sftrl_grid(ptr(Xd), ptr(yd), n, D, d, S, ptr(ms), ptr(etas), m_max, float(m0._thres), 0 if task == "cls" else 1,
+                                      ptr(BP), ptr(BN), ptr(counts), ptr(w), ptr(g_w), ptr(pred), ptr(status),
+                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if bool((status[:, 0] == 1).any().item()):
+            raise ValueError("Nan contained")
+        BPh, BNh, ch, ph = BP.cpu(), BN.cpu(), counts.cpu(), pred.cpu().numpy()
+        out = []
+        for s, (mdl, (_, m)) in enumerate(zip(models, settings)):
+            mdl.BT_P = BPh[s, :d * 2 * m].reshape(d, 2 * m).clone()
+            mdl.BT_N = BNh[s, :d * 2 * m].reshape(d, 2 * m).clone()
+            mdl.row_count_p, mdl.row_count_n = int(ch[s, 0]), int(ch[s, 1])
+            if cls._linear_term:
+                mdl.w, mdl.g_w = w[s].cpu().reshape(-1, 1), g_w[s].cpu().reshape(-1, 1)
+            out.append((mdl, ph[s].reshape((n,) + mdl._pred_shape(task == "cls"))))
+        return out
+
     def _pred_shape(self, cls):
         return (1,) if cls else ()

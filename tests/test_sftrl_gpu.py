@@ -101,3 +101,26 @@ def test_gpu_sketched_ftrl_limits_and_nan():
         m.online_learning()
     with pytest.raises(ValueError):
         classes()["SFTRL_CCFM"](torch.DoubleTensor(X), torch.DoubleTensor(y), "reg", 0.05, 4, device="tpu")
+
+
+@pytest.mark.parametrize("name,task", [("SFTRL_CCFM", "reg"), ("SFTRL_Vanila", "cls")])
+def test_gpu_sketched_ftrl_grid_equals_single_runs(name, task, golden_dir, capsys):
+    """fmx_sftrl_grid (Class.grid): every (learning_rate, m) setting of the grid over the reference's fixture stream equals its
+    own single run bit for bit, and the fixture's own setting (0.05, 4) reproduces the reference's predictions."""
+    z = np.load(os.path.join(golden_dir, "path_b_family.npz"))
+    cls = classes()[name]
+    X, y = torch.DoubleTensor(z[f"{task}/X"]), torch.DoubleTensor(z[f"{task}/y"])
+    lrs, ms = [0.01, 0.05, 0.2], [2, 4, 7, 16]
+    res = cls.grid(X, y, task, lrs, ms)
+    assert len(res) == 12
+    for (mdl, pred), (lr, m) in zip(res, [(a, b) for a in lrs for b in ms]):
+        one = cls(X, y, task, lr, m, device="gpu")
+        p1, _, _ = one.online_learning()
+        np.testing.assert_array_equal(pred, p1)
+        assert torch.equal(mdl.BT_P, one.BT_P) and torch.equal(mdl.BT_N, one.BT_N)
+        assert [mdl.row_count_p, mdl.row_count_n] == [one.row_count_p, one.row_count_n]
+        if name == "SFTRL_Vanila":
+            assert torch.equal(mdl.w, one.w) and torch.equal(mdl.g_w, one.g_w)
+        if (lr, m) == (0.05, 4):
+            np.testing.assert_allclose(pred, z[f"{task}/{name}/pred"].reshape(pred.shape), rtol=1e-7, atol=1e-9)
+    capsys.readouterr()
