@@ -1975,6 +1975,21 @@ __global__ __launch_bounds__(256) void k_online_mlp(OnlineMlpArgs a) {
     vocab[p] = live[p] ? (uint32_t)(a.foff[f + 1] - lo[p]) : 0u;
   }
   bool bad = false;
+  // wave 0: the NEXT sample's indices (and values) are requested while this one is processed -- they do not depend on the
+  // weights (as in k_fm_online); branch-free loads (see forward_sample)
+  const float *xsrc = a.xv ? a.xv : reinterpret_cast<const float *>(a.idx);
+  const bool has_x = a.xv != nullptr;
+  uint32_t l_n[NP];
+  float x_n[NP];
+  auto fetch_inputs = [&](int i) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const size_t o = (live[p] && i < a.N) ? (size_t)i * a.F + p * SLOTS + slot : (size_t)0;
+      l_n[p] = (uint32_t)a.idx[o];
+      x_n[p] = xsrc[o];
+    }
+  };
+  if (wave == 0) fetch_inputs(0);
   __syncthreads();
   for (int i = 0; i < a.N; ++i) {
     uint32_t li[NP];
@@ -1984,23 +1999,13 @@ __global__ __launch_bounds__(256) void k_online_mlp(OnlineMlpArgs a) {
     float4 S = splat(0.f);
     if (wave == 0) {
       // ---- the FM part: the arithmetic of k_fm_forward ----
-      // branch-free, all index loads before all row loads (see forward_sample / k_fm_online): with the loads of a pass under
+      // branch-free, all row loads together (see forward_sample / k_fm_online): with the loads of a pass under
       // `if (live[p])` a sample's rows went out in 2 NP dependent round trips
       {
-        const float *xsrc = a.xv ? a.xv : reinterpret_cast<const float *>(a.idx);
-        const bool has_x = a.xv != nullptr;
-        uint32_t l_[NP];
-        float x_[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          const size_t o = live[p] ? (size_t)i * a.F + p * SLOTS + slot : (size_t)0;
-          l_[p] = (uint32_t)a.idx[o];
-          x_[p] = xsrc[o];
-        }
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          li[p] = live[p] ? l_[p] : 0u;
-          x[p] = (has_x && live[p]) ? x_[p] : 1.f;
+          li[p] = live[p] ? l_n[p] : 0u;
+          x[p] = (has_x && live[p]) ? x_n[p] : 1.f;
           ok[p] = live[p] && li[p] < vocab[p];
         }
 #pragma unroll
@@ -2008,6 +2013,7 @@ __global__ __launch_bounds__(256) void k_online_mlp(OnlineMlpArgs a) {
           row[p] = load_row_sc1<LAYOUT>(a.rows + (size_t)(ok[p] ? lo[p] + li[p] : 0) * a.stride, q, kp, a.zoff);
           bad = bad || (live[p] && !ok[p]);
         }
+        fetch_inputs(i + 1);
       }
       float4 s = splat(0.f), ss = splat(0.f);
       float fo = 0.f;
