@@ -1980,7 +1980,8 @@ __global__ __launch_bounds__(256) void k_online_mlp(OnlineMlpArgs a) {
   const float *xsrc = a.xv ? a.xv : reinterpret_cast<const float *>(a.idx);
   const bool has_x = a.xv != nullptr;
   uint32_t l_n[NP];
-  float x_n[NP];
+  float x_n[NP], y_n = 0.f;
+  __shared__ float y_lds;  // the sample's label, for the MLP step (its own load of y would be one more exposed round trip)
   auto fetch_inputs = [&](int i) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -1988,6 +1989,7 @@ __global__ __launch_bounds__(256) void k_online_mlp(OnlineMlpArgs a) {
       l_n[p] = (uint32_t)a.idx[o];
       x_n[p] = xsrc[o];
     }
+    y_n = a.y[i < a.N ? i : 0];
   };
   if (wave == 0) fetch_inputs(0);
   __syncthreads();
@@ -2008,6 +2010,7 @@ __global__ __launch_bounds__(256) void k_online_mlp(OnlineMlpArgs a) {
           x[p] = (has_x && live[p]) ? x_n[p] : 1.f;
           ok[p] = live[p] && li[p] < vocab[p];
         }
+        if (lane == 0) y_lds = y_n;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           row[p] = load_row_sc1<LAYOUT>(a.rows + (size_t)(ok[p] ? lo[p] + li[p] : 0) * a.stride, q, kp, a.zoff);
@@ -2055,7 +2058,7 @@ __global__ __launch_bounds__(256) void k_online_mlp(OnlineMlpArgs a) {
     m.params = p_lds;
     m.bi = bi_lds;
     m.base = &base_lds;
-    m.y = a.y + i;
+    m.y = &y_lds;
     m.pred_out = a.pred + i;
     m.h = a.h;
     m.inv_b = 1.0f;
