@@ -20,28 +20,12 @@
 //
 // Everything is HBM / cache-line bound integer+fp32 work; there is no GEMM here and no MFMA.
 
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <atomic>
-#include <mutex>
-
-#include "fmx.h"
-
-// No floating-point contraction: every kernel evaluates the expressions as written (one rounding per operation), so two
-// kernels that state the same arithmetic -- k_fm_forward + k_fm_update at B = 1 and k_fm_online, the update with and
-// without the in-launch hand-off, ... -- give the same bits whatever the surrounding code looks like.  The kernels are
-// bound by memory round trips, not by VALU issue; fused multiply-adds are written explicitly where they are wanted.
-#pragma clang fp contract(off)
+#include "fmx_common.h"
 
 // ------------------------------------------------------------------------------------------------------------
-// host-side error plumbing
+// host-side error plumbing (shared by the translation units: fmx_common.h)
 // ------------------------------------------------------------------------------------------------------------
-namespace {
+namespace fmxd {
 
 thread_local char g_err[512] = "";
 
@@ -59,71 +43,9 @@ int check_launch(const char *what) {
   return FMX_OK;
 }
 
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+}  // namespace fmxd
 
-constexpr uint32_t SENT = 0xFFFFFFFFu;
-constexpr int WAVE = 64;
-constexpr int MAX_SORT_WIDTH = 32768;  // 128 KiB of the 160 KiB LDS
-
-// ------------------------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
-__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
-__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
-__device__ __forceinline__ float4 operator*(float a, float4 b) { return {a * b.x, a * b.y, a * b.z, a * b.w}; }
-__device__ __forceinline__ float4 splat(float a) { return {a, a, a, a}; }
-
-__device__ __forceinline__ float4 shfl_xor4(float4 v, int m) {
-  return {__shfl_xor(v.x, m), __shfl_xor(v.y, m), __shfl_xor(v.z, m), __shfl_xor(v.w, m)};
-}
-__device__ __forceinline__ float4 shfl_up4(float4 v, int d) {
-  return {__shfl_up(v.x, d), __shfl_up(v.y, d), __shfl_up(v.z, d), __shfl_up(v.w, d)};
-}
-__device__ __forceinline__ float4 shfl4(float4 v, int src) {
-  return {__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src), __shfl(v.w, src)};
-}
-
-// v_rcp_f32 / v_sqrt_f32 are 1-ulp instructions; the IEEE-exact expansions hipcc emits for `/` and sqrtf cost 10-14
-// VALU instructions each and made the FTRL kernels VALU-bound (profiles/r01_*).  1 ulp is ~1e-7 relative, two orders
-// below the 1e-5 parity tolerance.
-__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
-
-// FTRL-proximal weight from (z, n)  (McMahan et al. 2013, Algorithm 1); h.alpha holds 1/alpha on the device
-__device__ __forceinline__ float ftrl_w(float z, float n, const fmx_hyper_t &h) {
-  const float denom = fmaf(h.beta + sqrt_(n), h.alpha, h.l2);
-  const float w = -(z - copysignf(h.l1, z)) * rcp_(denom);
-  return fabsf(z) <= h.l1 ? 0.f : w;
-}
-__device__ __forceinline__ float4 ftrl_w4(float4 z, float4 n, const fmx_hyper_t &h) {
-  return {ftrl_w(z.x, n.x, h), ftrl_w(z.y, n.y, h), ftrl_w(z.z, n.z, h), ftrl_w(z.w, n.w, h)};
-}
-// one FTRL-proximal update of (z, n) by gradient g; w is the weight derived from the OLD (z, n)
-__device__ __forceinline__ void ftrl_upd(float &z, float &n, float w, float g, const fmx_hyper_t &h) {
-  const float n2 = fmaf(g, g, n);
-  const float sigma = (sqrt_(n2) - sqrt_(n)) * h.alpha;
-  z = fmaf(-sigma, w, z + g);
-  n = n2;
-}
-
-template <int RULE>
-__device__ __forceinline__ float apply_rule(float p, float g, const fmx_hyper_t &h) {
-  if (RULE == FMX_RULE_SIGNADAM) return p - h.lr * g * rcp_(fabsf(g) + h.eps);
-  return p - h.lr * g;  // FMX_RULE_SGD
-}
-template <int RULE>
-__device__ __forceinline__ float4 apply_rule4(float4 p, float4 g, const fmx_hyper_t &h) {
-  return {apply_rule<RULE>(p.x, g.x, h), apply_rule<RULE>(p.y, g.y, h), apply_rule<RULE>(p.z, g.z, h),
-          apply_rule<RULE>(p.w, g.w, h)};
-}
-
-__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
-// F.binary_cross_entropy_with_logits per element
-__device__ __forceinline__ float bcewl(float z, float y) {
-  return (1.f - y) * z + log1pf(expf(-fabsf(z))) + fmaxf(-z, 0.f);
-}
+namespace {
 
 // ------------------------------------------------------------------------------------------------------------
 // k_sort_occ
@@ -141,43 +63,7 @@ struct SortArgs {
   int32_t *error;
   int32_t B, F, Bp, bbits;  // F: number of SORT fields
   int32_t Fi;               // number of fields = columns of idx
-  // row prefetch (null: off): the sort runs batches ahead of the steps on a side stream and is the first to know which rows
-  // a batch will touch -- it requests one word of each of the row's lines, so that a row nobody has touched yet comes from HBM
-  // here and not on the critical path of k_fm_forward / k_fm_update (a fresh process, tables beyond the Infinity Cache)
-  const float *pf_rows;
-  int32_t pf_stride, pf_zoff;  // floats; pf_zoff > 0: the row has a second line (FTRL z | n)
 };
-
-// lane ^ M exchanges without the LDS crossbar (ds_bpermute made the sort LDS-pipe bound): DPP for M = 1, 2, 4, 8,
-// v_permlane16/32_swap for M = 16, 32.
-template <int M>
-__device__ __forceinline__ uint32_t xor_lane(uint32_t v, int lane) {
-  if constexpr (M == 1) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-  } else if constexpr (M == 2) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-  } else if constexpr (M == 4) {
-    const int t = __builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);     // row_half_mirror: i -> 7 - i
-    return (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x1B, 0xF, 0xF, true);         // quad_perm [3,2,1,0]: together i ^ 4
-  } else if constexpr (M == 8) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
-  } else if constexpr (M == 16) {
-    const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // {[r0,r0,r2,r2], [r1,r1,r3,r3]}
-    return (lane & 16) ? sw[0] : sw[1];
-  } else {
-    const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // {[lo,lo], [hi,hi]}
-    return (lane & 32) ? sw[0] : sw[1];
-  }
-}
-
-template <int M>
-__device__ __forceinline__ float xor_lane_f(float v, int lane) {
-  return __uint_as_float(xor_lane<M>(__float_as_uint(v), lane));
-}
-template <int M>
-__device__ __forceinline__ float4 xor_lane_f4(float4 v, int lane) {
-  return {xor_lane_f<M>(v.x, lane), xor_lane_f<M>(v.y, lane), xor_lane_f<M>(v.z, lane), xor_lane_f<M>(v.w, lane)};
-}
 
 // Bitonic network on N = Bp composites held E per thread in a blocked layout (element i = tid * E + r):
 //   partner distance j <  E        in-thread compare-exchange
@@ -239,7 +125,6 @@ __device__ __forceinline__ void load_composites(const SortArgs &a, int f, int i0
     li[r] = (uint32_t)a.idx[(size_t)(i < a.B ? i : a.B - 1) * a.Fi + col];
   }
   bool bad = false;
-  float pf = 0.f;
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const int i = i0 + r;
@@ -247,14 +132,8 @@ __device__ __forceinline__ void load_composites(const SortArgs &a, int f, int i0
     const bool mine = i < a.B && lp < piece_rows;
     v[r] = mine ? ((lp << a.bbits) | (uint32_t)i) : SENT;
     bad = bad || (i < a.B && li[r] >= field_rows);
-    if (a.pf_rows && mine) {  // touch the row's line(s); the values only keep the loads alive
-      const float *rp = a.pf_rows + (size_t)(a.soff[f] + lp) * a.pf_stride;
-      pf += __builtin_nontemporal_load(rp);
-      if (a.pf_zoff > 0) pf += __builtin_nontemporal_load(rp + a.pf_zoff);
-    }
   }
   if (bad && a.error) *a.error = 1;
-  if (a.pf_rows && __float_as_uint(pf) == 0x7FBADBADu && a.error) *a.error = 0x7FFFFFFF;  // never true in practice: keeps the prefetch loads
 }
 
 // Device body of the occurrence sort of ONE field (the calling workgroup: nt threads, nt * E == Bp): the full bitonic
@@ -858,85 +737,10 @@ struct UpdArgs {
 // tile meta states
 constexpr int LEAD_NONE = 0, LEAD_CLOSES = 1, LEAD_THROUGH = 2;
 
-// deterministic block reduction of src[0..n): every thread sums a strided set of elements (16-byte groups when dense),
-// 16 independent loads in flight per round -- at B = 16,384 with 128 threads a 4-deep unroll left 32 dependent rounds of
-// HBM latency per sum and the one workgroup that owns the bias became the longest path of the launch -- then an LDS tree.
-// The order of the additions depends only on (n, ld == 1, min(blockDim, 128)): at most 128 threads take part, so that
-// the 256-thread workgroups of the fused step launch and the default 128-thread ones of k_fm_update give identical bits.
-__device__ float block_sum(const float *src, int n, int ld, float *sm) {
-  constexpr int U = 16;
-  const int tid = threadIdx.x, nt = blockDim.x < 128 ? blockDim.x : 128;
-  float acc = 0.f;
-  if (tid >= nt) {  // bystanders of a wider workgroup: only the barriers
-    __syncthreads();
-    for (int w = nt >> 1; w > 0; w >>= 1) __syncthreads();
-    const float r = sm[0];
-    __syncthreads();
-    return r;
-  }
-  if (ld == 1) {
-    const int n4 = n >> 2;
-    const float4 *src4 = reinterpret_cast<const float4 *>(src);
-    for (int i0 = tid; i0 < n4; i0 += U * nt) {
-      float4 v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {  // branch-free: a group beyond the end reads group 0 and counts as zeros (a branch per
-        const int i = i0 + u * nt;   // load made the compiler wait for every load before it issued the next)
-        v[u] = src4[i < n4 ? i : 0];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool in = i0 + u * nt < n4;
-        acc += in ? (v[u].x + v[u].y) + (v[u].z + v[u].w) : 0.f;
-      }
-    }
-    for (int i = (n4 << 2) + tid; i < n; i += nt) acc += src[i];
-  } else {  // strided sample records: the SAME order of additions as the dense form (groups of four elements, then the
-            // tail), so a step over gathered records and a step over dense arrays give identical bits
-    constexpr int V = 4;
-    const int n4 = n >> 2;
-    for (int i0 = tid; i0 < n4; i0 += V * nt) {
-      float4 v[V];
-#pragma unroll
-      for (int u = 0; u < V; ++u) {
-        const int i = i0 + u * nt;
-        const float *p = src + (size_t)(4 * (i < n4 ? i : 0)) * ld;
-        v[u] = float4{p[0], p[ld], p[2 * (size_t)ld], p[3 * (size_t)ld]};
-      }
-#pragma unroll
-      for (int u = 0; u < V; ++u) {
-        const bool in = i0 + u * nt < n4;
-        acc += in ? (v[u].x + v[u].y) + (v[u].z + v[u].w) : 0.f;
-      }
-    }
-    for (int i = (n4 << 2) + tid; i < n; i += nt) acc += src[(size_t)i * ld];
-  }
-  sm[tid] = acc;
-  __syncthreads();
-  for (int w = nt >> 1; w > 0; w >>= 1) {
-    if (tid < w) sm[tid] += sm[tid + w];
-    __syncthreads();
-  }
-  const float r = sm[0];
-  __syncthreads();
-  return r;
-}
+__device__ __forceinline__ void st16(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void st4(float *p, float v) { *p = v; }
 
-// WT: write-through (sc1) stores -- the fused step launch hands the updated rows to the next batch's forward waves of the
-// same launch, which read them with sc1 loads (MI355X_MICROARCH.md, "Valid forms": sc1 on both sides, the storing wave's
-// s_waitcnt vmcnt(0) before it signals)
-template <bool WT>
-__device__ __forceinline__ void st16(float *p, float4 v) {
-  if (WT) st_sc1_4(p, v);
-  else *reinterpret_cast<float4 *>(p) = v;
-}
-template <bool WT>
-__device__ __forceinline__ void st4(float *p, float v) {
-  if (WT) st_sc1(p, v);
-  else *p = v;
-}
-
-template <int LAYOUT, int RULE, bool WT = false>
+template <int LAYOUT, int RULE>
 __device__ void bias_and_loss(const UpdArgs &a) {
   __shared__ float sm[256];
   const float db = block_sum(a.dz_first, a.B, a.ld1, sm);
@@ -944,13 +748,13 @@ __device__ void bias_and_loss(const UpdArgs &a) {
   if (a.loss_b && a.loss_out) ls = block_sum(a.loss_b, a.B, a.ld1, sm);
   if (threadIdx.x == 0) {
     if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
-      st4<WT>(a.bias, apply_rule<RULE>(a.bias[0], db, a.h));
+      st4(a.bias, apply_rule<RULE>(a.bias[0], db, a.h));
     } else {
       float z = a.bias[0], n = a.bias[1];
       const float w = ftrl_w(z, n, a.h);
       ftrl_upd(z, n, w, db, a.h);
-      st4<WT>(a.bias, z);
-      st4<WT>(a.bias + 1, n);
+      st4(a.bias, z);
+      st4(a.bias + 1, n);
     }
     if (a.loss_b && a.loss_out) {
       int i = 0;
@@ -993,15 +797,15 @@ __device__ __forceinline__ RowRegs load_row(const float *rp, int q, int kp, int 
 }
 
 // gradient of the row from the run sums (dV = cV - V * cA, dw = cw), one application of the rule, store
-template <int LAYOUT, int RULE, bool WT = false>
+template <int LAYOUT, int RULE>
 __device__ __forceinline__ void update_row(float *rp, int q, int kp, int zoff, RowRegs r, float4 cV, float4 cA, float cw,
                                            const fmx_hyper_t &h) {
   // two roundings on purpose (no fma): where a sample is the row's only contribution to S (x = 1), cV = dz * V and
   // V * cA = V * dz round alike and the gradient is exactly 0, as in the reference's dz * x * (S - e)
   const float4 gr = cV - r.v * cA;
   if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
-    st16<WT>(rp + 4 * q, apply_rule4<RULE>(r.v, gr, h));
-    if (q == 0) st4<WT>(rp + kp, apply_rule<RULE>(r.fo.x, cw, h));
+    st16(rp + 4 * q, apply_rule4<RULE>(r.v, gr, h));
+    if (q == 0) st4(rp + kp, apply_rule<RULE>(r.fo.x, cw, h));
   } else {
     float4 z4 = r.z, n4 = r.n;
     ftrl_upd(z4.x, n4.x, r.v.x, gr.x, h);
@@ -1011,12 +815,12 @@ __device__ __forceinline__ void update_row(float *rp, int q, int kp, int zoff, R
     // the (z, n) half is read by nobody but the next update of this row (a later launch): plain stores
     *reinterpret_cast<float4 *>(rp + zoff + 4 * q) = z4;
     *reinterpret_cast<float4 *>(rp + zoff + kp + 4 * q) = n4;
-    st16<WT>(rp + 4 * q, ftrl_w4(z4, n4, h));
+    st16(rp + 4 * q, ftrl_w4(z4, n4, h));
     if (q == 0) {
       float4 fo = r.fo;
       ftrl_upd(fo.y, fo.z, fo.x, cw, h);
       fo.x = ftrl_w(fo.y, fo.z, h);
-      st16<WT>(rp + kp, fo);
+      st16(rp + kp, fo);
     }
   }
 }
@@ -1049,7 +853,7 @@ template <> struct CoefA<false> {
 // walks EPG = 64 / SLOTS CONSECUTIVE occurrences sequentially, so duplicates inside a group are summed in registers;
 // one segmented scan over the SLOTS groups (log2(SLOTS) steps of wave shuffles) carries the sums of runs that span
 // groups.  At the tail of a run: the row update when the run began in this tile, a partial record otherwise.
-template <int LPR, int LAYOUT, int RULE, bool HAS_GBI, bool INL, bool WT>
+template <int LPR, int LAYOUT, int RULE, bool HAS_GBI, bool INL>
 __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   constexpr int SLOTS = WAVE / LPR;  // lane groups
   constexpr int EPG = LPR;           // consecutive occurrences per group
@@ -1057,7 +861,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   constexpr bool PREFETCH_ROWS = EPG <= 4;
   using CA = CoefA<HAS_GBI>;
   if (blk == 0) {  // the first block (dispatched first) owns the bias and the loss reduction
-    bias_and_loss<LAYOUT, RULE, WT>(a);
+    bias_and_loss<LAYOUT, RULE>(a);
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -1282,7 +1086,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
       if (k[j] != tile_prevkey) {
         float *rp = a.rows + (row0 + k[j]) * (size_t)a.stride;
         const RowRegs r = PREFETCH_ROWS ? row[PREFETCH_ROWS ? j : 0] : load_row<LAYOUT>(rp, q, kp, a.zoff);
-        update_row<LAYOUT, RULE, WT>(rp, q, kp, a.zoff, r, accV, accA.vec(), accw, a.h);
+        update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, accV, accA.vec(), accw, a.h);
       } else {
         // the run that came in from the previous tile ends here: its part inside this tile stays in registers for this
         // wave's combine below (INL), or goes to memory for k_fm_fixup
@@ -1363,162 +1167,14 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
     aA = aA + shfl_xor4(aA, mm);
     aw += __shfl_xor(aw, mm);
   }
-  if (lane < LPR) update_row<LAYOUT, RULE, WT>(rp, q, kp, a.zoff, r, aV, aA, aw, a.h);
+  if (lane < LPR) update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, aV, aA, aw, a.h);
 }
 
 template <int LPR, int LAYOUT, int RULE, bool HAS_GBI, bool INL>
 __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   __builtin_amdgcn_s_setprio(3);  // ahead of the side-stream sort's waves at the CU's instruction arbiter
-  update_body<LPR, LAYOUT, RULE, HAS_GBI, INL, false>(a, blockIdx.x);
+  update_body<LPR, LAYOUT, RULE, HAS_GBI, INL>(a, blockIdx.x);
 }
-
-// ------------------------------------------------------------------------------------------------------------
-// k_fm_fused: update(s) and forward(s + 1) in ONE launch (the online loop's steady state: one launch per step)
-// ------------------------------------------------------------------------------------------------------------
-// In the loop of fmx_fm_stream step s is forward(s) -> update(s), two dependent launches: ~7.5 + ~12 us of kernels whose
-// critical paths are chains of dependent round trips, plus two launch boundaries.  Here the blocks of update(s) come
-// first in the grid and the waves of forward(s + 1) behind them, FUSE_SPW samples per wave: a forward wave fetches its
-// indices and labels at once, then waits until every update wave of the launch has arrived at a counter (each after
-// its s_waitcnt vmcnt(0), i.e. with its row stores acknowledged), and only then gathers its rows -- with sc1 loads, the
-// update's row stores of this launch being write-through (sc1): the hand-off form of MI355X_MICROARCH.md "Valid forms"
-// (sc1 both sides, storing wave drained before it signals, one wave of the consumer workgroup polls relaxed and the
-// others load behind a workgroup barrier it then joins).  What is saved: a launch boundary, the forward's launch ramp
-// and its index round trip.  The arithmetic is that of k_fm_update and k_fm_forward: identical bits.
-// Progress: update waves wait for nothing but lower-numbered update tiles (the in-launch hand-off of crossing runs), so
-// they finish whatever the forward waves do; the grid is sized so that ALL of it is resident at once (host: occupancy
-// query), the wait is bounded (error flag 3), and workgroups are dispatched in index order.
-constexpr int FUSE_SHARDS = 16;  // arrival counters, each on a 128-byte line of its own
-constexpr int FUSE_SPW = 4;      // samples per forward wave
-struct FuseArgs {
-  uint32_t *done;        // [FUSE_SHARDS][32]: word 0 of every line counts arrivals; zeroed at the start of the stream call
-  uint32_t target;       // arrivals once the update workgroups of THIS launch are done: (fused launches so far + 1) * workgroups
-  uint32_t rows_bytes;   // size of the table (buffer loads range-check against it)
-  int32_t n_upd_blocks;
-  int32_t first_sleep, poll_sleep;  // in s_sleep units of 64 clocks: before the first poll, and between polls
-  int32_t debug;                    // timing experiments (wrong results): 4 workgroups arrive BEFORE their update, 5 no gather
-  unsigned long long *stamps;       // debug 6: [workgroup][4] s_memrealtime (100 MHz) at start / arrival or poll match / end
-};
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-template <int LPR, int LAYOUT, int RULE, int NPASS, int AUX>
-__global__ __launch_bounds__(1024, 4) void k_fm_fused(UpdArgs u, FwdArgs a, FuseArgs z) {  // 4 waves per SIMD: <= 128 VGPRs
-  __builtin_amdgcn_s_setprio(3);
-  const int lane = threadIdx.x & 63;
-  if (z.stamps && threadIdx.x == 0) z.stamps[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
-  if ((int)blockIdx.x < z.n_upd_blocks) {
-    if (z.debug == 4 && threadIdx.x == 0)
-      (void)__hip_atomic_fetch_add(z.done + (blockIdx.x % FUSE_SHARDS) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    update_body<LPR, LAYOUT, RULE, false, true, true>(u, (int)blockIdx.x);
-    if (z.debug == 4) return;
-    // every store of every wave of the workgroup is acknowledged before the workgroup counts as done: one arrival per
-    // workgroup (a counter word takes ~90 atomics per microsecond; one per wave was 2,500 of them per launch)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      (void)__hip_atomic_fetch_add(z.done + (blockIdx.x % FUSE_SHARDS) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (z.stamps) z.stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-    }
-    return;
-  }
-  constexpr int SLOTS = WAVE / LPR, NP = NPASS, SPW = FUSE_SPW;
-  const int slot = lane / LPR, q = lane % LPR;
-  const int kp = LPR * 4;
-  const int b0 = (((int)blockIdx.x - z.n_upd_blocks) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) * SPW;
-  // ---- phase A (beside the update waves): everything that does not depend on the table ----
-  int64_t lo[NP];
-  uint32_t vocab[NP];
-  bool live[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int f = p * SLOTS + slot;
-    live[p] = f < a.F;
-    lo[p] = live[p] ? a.foff[f] : 0;
-    vocab[p] = live[p] ? (uint32_t)(a.foff[f + 1] - lo[p]) : 0u;
-  }
-  uint32_t li[SPW][NP];
-  float yv[SPW];
-#pragma unroll
-  for (int i = 0; i < SPW; ++i) {
-    const int b = b0 + i;
-    const bool valid = b < a.B;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) li[i][p] = (valid && live[p]) ? (uint32_t)a.idx[(size_t)b * a.F + p * SLOTS + slot] : 0u;
-    yv[i] = valid ? a.y[b] : 0.f;
-  }
-  // ---- wait for the update waves of this launch: wave 0 of the workgroup polls, the others wait at the barrier ----
-  if (threadIdx.x < 64) {
-    // the update takes several microseconds: no poll before that (every poll is a request to the counters' lines, which
-    // the arrivals need), then one poll per poll_sleep
-    for (int i = 0; i < z.first_sleep; ++i) __builtin_amdgcn_s_sleep(1);
-    for (unsigned spin = 0;; ++spin) {
-      uint32_t c = lane < FUSE_SHARDS ? __hip_atomic_load(z.done + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-      for (int m = 1; m < FUSE_SHARDS; m <<= 1) c += __shfl_xor(c, m);
-      if (__shfl(c, 0) >= z.target) break;
-      if (spin >= (1u << 20)) {
-        if (lane == 0 && u.error) *u.error = 3;
-        break;
-      }
-      for (int i = 0; i < z.poll_sleep; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-    if (z.stamps && threadIdx.x == 0) z.stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-  }
-  if (AUX == 0 && threadIdx.x < 64) {
-    // ONE agent-scope acquire per workgroup, by the wave that polled: drops this CU's L1 lines (rows read before the
-    // update); the wait holds the barrier below until the invalidate has completed.  The gather then uses PLAIN loads, so
-    // the hot rows of the small fields -- read by thousands of samples -- are served by L1 / L2 (sc1 loads of every row go
-    // past the caches to the memory side, where 4,096 reads of one line queue up: 16 us instead of 3 for the gather)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  asm volatile("" ::: "memory");
-  // ---- phase B: the gather ----
-  const float bias0 = ld_sc1(a.bias);
-  const float bias1 = LAYOUT == FMX_LAYOUT_WEIGHTS ? 0.f : ld_sc1(a.bias + 1);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.rows), 0, (int)z.rows_bytes, 0x00020000);
-  float4 r0[SPW][NP];
-  float rw[SPW][NP];
-#pragma unroll
-  for (int i = 0; i < SPW; ++i) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      r0[i][p] = splat(0.f);
-      rw[i][p] = 0.f;
-      if (b0 + i < a.B && live[p] && li[i][p] < vocab[p] && z.debug != 5) {
-        const uint32_t off = (uint32_t)(((size_t)(lo[p] + li[i][p]) * a.stride + 4 * q) * sizeof(float));
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX);  // aux 0 = plain (behind the acquire), 16 = sc1
-        r0[i][p] = {__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
-        if (q == 0) rw[i][p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + kp * sizeof(float), 0, AUX));
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < SPW; ++i) {
-    const int b = b0 + i;
-    if (b >= a.B) break;  // wave-uniform
-    float4 s = splat(0.f), ss = splat(0.f);
-    float fo = 0.f;
-    bool bad = false;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      if (live[p]) {
-        if (li[i][p] < vocab[p]) {
-          const float4 e = 1.f * r0[i][p];  // x == 1 (fmx_fm_stream has no feature values)
-          s = s + e;
-          ss = ss + e * e;
-          fo += rw[i][p] * 1.f;
-        } else {
-          bad = true;
-        }
-      }
-    }
-    forward_finish<LPR, LAYOUT>(a, b, lane, s, ss, fo, bad, yv[i], bias0, bias1);
-  }
-  if (z.stamps && threadIdx.x == 0) z.stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-}
-
 
 // ------------------------------------------------------------------------------------------------------------
 // k_fm_online: the reference's online protocol on a device-resident stream (pure FM)
@@ -2197,30 +1853,8 @@ int check_sort_geometry(const fmx_table_t *t, int B) {
   return FMX_OK;
 }
 
-// ---- launch geometry knobs (waves per workgroup), overridable from the environment for experiments ----
-struct Tune {
-  int wpb_fwd = 2, wpb_upd = 2;  // waves per workgroup (FMX_WPB_FWD / FMX_WPB_UPD: 1, 2 or 4; a 3 x 3 sweep is flat within 1 %)
-  int sort_e = 0;     // FMX_SORT_E: elements per thread of the bitonic sort (0 = default)
-  int inline_fixup = 1;  // FMX_INLINE_FIXUP=0 / fmx_set_option("inline_fixup", 0): partial records are combined by a second
-                         // launch (k_fm_fixup) instead of the in-launch hand-off; both give identical bits
-  int online_persistent = 1;  // FMX_ONLINE_PERSISTENT=0 / fmx_set_option("online_persistent", 0): fmx_online_run_mlp as per-sample launches
-  int sort_ahead = 8;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..8)
-  int fused_step = 0;    // FMX_FUSED_STEP=1 / fmx_set_option("fused_step", 1): fmx_fm_stream launches update(s) + forward(s + 1) as ONE
-                         // launch (k_fm_fused) instead of separately; identical bits; measured slower, so off
-  int sort_prefetch = 0;      // FMX_SORT_PREFETCH=1 / fmx_set_option("sort_prefetch", 1): the sort touches the rows of its batch (a
-                              // software prefetch from the stage that runs ahead).  Measured SLOWER -- fresh 20-step run 39.4 vs
-                              // 33.5 us/step, steady state 28.2 vs 24.0: the sort waits for its 8 extra loads per thread and the
-                              // two streams then fight for the same lines -- so off
-  int mlp_chain = 1;          // FMX_MLP_CHAIN=0 / fmx_set_option("mlp_chain", 0): fmx_mlp_section as separate GEMM launches
-                              // (forward x L, loss, dgrad x L) instead of k_mlp_chain; same results up to summation order
-  int fused_debug = 0;        // FMX_FUSED_DEBUG (timing experiments, wrong results): 1 no forward workgroups, 2 forward does not wait
-  int fused_wpb = 4;          // FMX_FUSED_WPB: waves per workgroup of k_fm_fused (4 or 16)
-  int fused_first_sleep = 64; // FMX_FUSED_FIRST_SLEEP: s_sleep units (64 clocks) a forward workgroup waits before its first poll
-  int fused_poll_sleep = 8;   // FMX_FUSED_POLL_SLEEP: s_sleep units between polls
-  int sort_chunked = 1;  // FMX_SORT_CHUNKED / fmx_set_option("sort_chunked", v): 0: one workgroup per field (k_sort_occ) at
-                         // every width; 1: k_sort_chunk + k_sort_merge from 8,192 composites per field on; 2: from 2,048 on.
-                         // Identical lists either way
-};
+}  // namespace
+namespace fmxd {
 Tune &tune() {
   static Tune t = [] {
     Tune x;
@@ -2231,13 +1865,7 @@ Tune &tune() {
     if (const char *e = getenv("FMX_ONLINE_PERSISTENT")) x.online_persistent = atoi(e);
     if (const char *e = getenv("FMX_INLINE_FIXUP")) x.inline_fixup = atoi(e);
     if (const char *e = getenv("FMX_SORT_CHUNKED")) x.sort_chunked = atoi(e);
-    if (const char *e = getenv("FMX_FUSED_STEP")) x.fused_step = atoi(e);
-    if (const char *e = getenv("FMX_FUSED_DEBUG")) x.fused_debug = atoi(e);
     if (const char *e = getenv("FMX_MLP_CHAIN")) x.mlp_chain = atoi(e);
-    if (const char *e = getenv("FMX_SORT_PREFETCH")) x.sort_prefetch = atoi(e);
-    if (const char *e = getenv("FMX_FUSED_WPB")) x.fused_wpb = atoi(e) == 16 ? 16 : 4;
-    if (const char *e = getenv("FMX_FUSED_FIRST_SLEEP")) x.fused_first_sleep = atoi(e);
-    if (const char *e = getenv("FMX_FUSED_POLL_SLEEP")) x.fused_poll_sleep = atoi(e);
     auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
     if (!ok(x.wpb_fwd)) x.wpb_fwd = 2;
     if (!ok(x.wpb_upd)) x.wpb_upd = 2;
@@ -2245,6 +1873,8 @@ Tune &tune() {
   }();
   return t;
 }
+}  // namespace fmxd
+namespace {
 
 constexpr int SORT_AHEAD_MAX = 8;  // batches sorted per side-stream launch in fmx_fm_stream
 
@@ -2257,15 +1887,10 @@ struct Workspace {
   int32_t *meta;
   int32_t *counter;  // step counter (one int32 in its own 256-byte slot; unused by the current loop)
   float *parts;
-  uint32_t *done;    // FUSE_SHARDS x 128 bytes: arrival counters of the fused step launch
-  float *fwd2;       // [B, kp] S | [B] dz | [B] loss: the second set of forward outputs of the fused loop (ping-pong)
   size_t bytes;
 };
 
-size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-#include "fmx_mlp_gemm.inc"
-#include "fmx_sftrl.inc"
 
 Workspace carve(const fmx_table_t *t, int B, void *base) {
   const size_t F = (size_t)n_sort_fields(t), Bp = (size_t)fmx_sorted_width(B), tiles = Bp >> 6;
@@ -2283,11 +1908,7 @@ Workspace carve(const fmx_table_t *t, int B, void *base) {
   w.meta = reinterpret_cast<int32_t *>(p + o_meta);
   w.counter = reinterpret_cast<int32_t *>(p + o_counter);
   w.parts = reinterpret_cast<float *>(p + o_parts);
-  const size_t o_done = o_parts + align_up(F * tiles * 2 * rec * 4, 256);
-  const size_t o_fwd2 = o_done + (size_t)FUSE_SHARDS * 128;
-  w.done = reinterpret_cast<uint32_t *>(p + o_done);
-  w.fwd2 = reinterpret_cast<float *>(p + o_fwd2);
-  w.bytes = o_fwd2 + align_up(((size_t)B * t->kp + 2 * align_up((size_t)B, 4)) * 4, 256);
+  w.bytes = o_parts + align_up(F * tiles * 2 * rec * 4, 256);
   return w;
 }
 
@@ -2401,78 +2022,6 @@ void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st
   launch_fixup<LPR>(a, rule, st);
 }
 
-// k_fm_fused is built for the kp = 16 row (4 lanes per row) and up to 64 fields; -1: not eligible.  Otherwise the number of
-// forward workgroups of a launch; the whole grid must be resident at once (see the kernel's comment).
-using FusedFn = void (*)(UpdArgs, FwdArgs, FuseArgs);
-template <int AUX>
-FusedFn fused_kernel_aux(int rule, int np) {
-  switch (rule) {
-    case FMX_RULE_SIGNADAM:
-      switch (np) {
-        case 1: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, 1, AUX>;
-        case 2: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, 2, AUX>;
-        case 3: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, 3, AUX>;
-        default: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, 4, AUX>;
-      }
-    case FMX_RULE_SGD:
-      switch (np) {
-        case 1: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, 1, AUX>;
-        case 2: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, 2, AUX>;
-        case 3: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, 3, AUX>;
-        default: return k_fm_fused<4, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, 4, AUX>;
-      }
-    default:
-      switch (np) {
-        case 1: return k_fm_fused<4, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, 1, AUX>;
-        case 2: return k_fm_fused<4, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, 2, AUX>;
-        case 3: return k_fm_fused<4, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, 3, AUX>;
-        default: return k_fm_fused<4, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, 4, AUX>;
-      }
-  }
-}
-// fused_step 1: one agent acquire per forward workgroup + plain gather loads (default); 2: sc1 gather loads, no acquire
-FusedFn fused_kernel(int rule, int np) { return tune().fused_step == 2 ? fused_kernel_aux<16>(rule, np) : fused_kernel_aux<0>(rule, np); }
-
-// Is the one-launch step usable for this table and batch on the current device?  (kp = 16, <= 64 fields, a table the
-// 32-bit buffer offsets reach, the in-launch hand-off enabled, and the WHOLE grid resident at once.)
-bool fused_eligible(const fmx_table_t *table, int32_t B, int rule, hipStream_t st) {
-  if (!tune().fused_step || !tune().inline_fixup || is_capturing(st)) return false;
-  if (table->kp != 16 || table->n_fields > 64 || B < OVERLAP_MIN_BATCH) return false;
-  if ((uint64_t)table->n_rows * (uint64_t)table->row_stride * 4ull >= (1ull << 32)) return false;
-  const int np = (table->n_fields + 15) / 16;
-  const int tiles = n_sort_fields(table) * (fmx_sorted_width(B) >> 6);
-  const int wpb = tune().fused_wpb;
-  const int n_blocks = 1 + (tiles + wpb - 1) / wpb + (B + wpb * FUSE_SPW - 1) / (wpb * FUSE_SPW);
-  int dev = 0, cus = 0, per_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return false;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(fused_kernel(rule, np)), 64 * wpb, 0) != hipSuccess)
-    return false;
-  // (register-limited at 4 workgroups per CU, where the occupancy query is exact: MI355X_MICROARCH.md, "Residency")
-  return (long long)n_blocks <= (long long)cus * per_cu;
-}
-
-int fused_impl(const fmx_table_t *table, int rule, const UpdArgs &u, const FwdArgs &f, const Workspace &w, uint32_t launches_before,
-               hipStream_t st, unsigned long long *stamps = nullptr) {
-  const int np = (table->n_fields + 15) / 16;
-  const int tiles = u.F * (u.Bp >> 6);
-  const int wpb = tune().fused_wpb;
-  FuseArgs z;
-  z.done = w.done;
-  z.n_upd_blocks = 1 + (tiles + wpb - 1) / wpb;
-  z.target = (launches_before + 1u) * (uint32_t)z.n_upd_blocks;
-  z.rows_bytes = (uint32_t)((uint64_t)table->n_rows * (uint64_t)table->row_stride * 4ull);
-  z.first_sleep = tune().fused_first_sleep;
-  z.poll_sleep = tune().fused_poll_sleep;
-  z.debug = tune().fused_debug;
-  z.stamps = stamps;
-  int n_fwd = (f.B + wpb * FUSE_SPW - 1) / (wpb * FUSE_SPW);
-  if (tune().fused_debug == 1) n_fwd = 0;      // timing experiments only (results are wrong): the update part alone
-  if (tune().fused_debug == 2) z.target = 0;   // ... the forward part does not wait
-  hipLaunchKernelGGL(fused_kernel(rule, np), dim3(z.n_upd_blocks + n_fwd), dim3(64 * wpb), 0, st, u, f, z);
-  return check_launch("k_fm_fused");
-}
-
 template <int E>
 void launch_sort(const SortArgs &a, hipStream_t st) {
   const int threads = a.Bp / E;
@@ -2535,9 +2084,6 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
   a.Fi = table->n_fields;
   a.Bp = fmx_sorted_width(B);
   a.bbits = fmx_sorted_bbits(B);
-  a.pf_rows = tune().sort_prefetch ? table->rows : nullptr;
-  a.pf_stride = table->row_stride;
-  a.pf_zoff = table->layout == FMX_LAYOUT_FTRL ? table->z_offset : 0;
   // the chunked form wins on LATENCY (one or two batches per launch: the prefetched global sorts of the multi-GPU modes, a
   // single step); a launch of many batches fills the chip either way and the rank merge then costs more work than the
   // bitonic stages it replaces (8 batches of 16,384: 294 vs 118 us)
@@ -2787,9 +2333,7 @@ int fmx_set_option(const char *name, int value) {
   else if (!strcmp(name, "sort_ahead")) slot = &t.sort_ahead;
   else if (!strcmp(name, "online_persistent")) slot = &t.online_persistent;
   else if (!strcmp(name, "sort_chunked")) slot = &t.sort_chunked;
-  else if (!strcmp(name, "fused_step")) slot = &t.fused_step;
   else if (!strcmp(name, "mlp_chain")) slot = &t.mlp_chain;
-  else if (!strcmp(name, "sort_prefetch")) slot = &t.sort_prefetch;
   else return fail(FMX_ERR_ARG, "fmx_set_option: unknown option '%s'", name);
   const int old = *slot;
   *slot = value;
@@ -2959,7 +2503,7 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     // launch on the side stream while the previous group runs forward / update / fixup on `stream`.  Ring of
     // 2 * ahead sorted buffers; per group one sort launch and four event operations, so the host issues ~3.6 runtime
     // calls per step instead of 8 (at ~4 us each the per-batch version was host-bound).
-    Side *sd = (B >= OVERLAP_MIN_BATCH && n_steps > 0 && tune().fused_debug != 3) ? side_for_current_device() : nullptr;  // debug 3: the sorts on `stream` itself
+    Side *sd = (B >= OVERLAP_MIN_BATCH && n_steps > 0) ? side_for_current_device() : nullptr;
     hipStream_t user = st;
     const bool detour = sd && st == nullptr;  // the legacy default stream cannot be captured / is slow to enqueue on
     if (detour) {
@@ -2977,18 +2521,6 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     int ahead = tune().sort_ahead;
     if (ahead < 1) ahead = 1;
     if (ahead > SORT_AHEAD_MAX) ahead = SORT_AHEAD_MAX;
-    // ---- the one-launch step (k_fm_fused) where the table, the batch and the device allow it ----
-    const bool fused = n_steps > 1 && fwd->sample_ld == 0 && fused_eligible(table, B, rule, st);
-    uint32_t n_fused = 0;
-    fmx_fwd_out_t alt = *fwd;  // the second set of forward outputs lives in the workspace
-    alt.S = w.fwd2;
-    alt.dz = w.fwd2 + (size_t)B * table->kp;
-    alt.loss = alt.dz + align_up((size_t)B, 4);
-    alt.bi = alt.first = alt.sfirst = alt.sbi = alt.logit = nullptr;
-    fmx_fwd_out_t mine = *fwd;
-    mine.bi = mine.first = mine.sfirst = mine.sbi = mine.logit = nullptr;
-    auto fwd_set = [&](int s) -> const fmx_fwd_out_t * { return ((n_steps - 1 - s) & 1) ? &alt : &mine; };
-    if (fused) (void)hipMemsetAsync(w.done, 0, (size_t)FUSE_SHARDS * 128, st);
     // group g holds min(2^g, ahead) batches: the first sort (one batch) runs beside the first forward pass and exposes only
     // its own ~19 us instead of a whole group's 30; the pipeline is at full depth from the fourth group on.  Group g uses
     // half (g & 1) of the ring of 2 * ahead sorted buffers.
@@ -3031,33 +2563,11 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
         const int32_t *idx = idx_pool + (size_t)j * B * F;
         const float *y = y_pool + (size_t)j * B;
         const uint32_t *sorted = w.sorted + ((size_t)(g & 1) * ahead + i) * w.sorted_stride;
-        if (!fused) {
-          rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
-          if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
-          if (rc == FMX_OK)
-            rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
-                             loss_out ? loss_out + s : nullptr, st, nullptr, fwd->sample_ld, fwd->error);
-          continue;
-        }
-        // one launch per step: update(s) + forward(s + 1) (k_fm_fused); the forward outputs ping-pong between the caller's
-        // buffers and the workspace's second set, the LAST step using the caller's
-        const fmx_fwd_out_t *cur = fwd_set(s), *nxt = fwd_set(s + 1);
-        if (s == 0) rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, cur, st);
+        rc = forward_impl(table, hyper, idx, nullptr, y, B, loss_kind, inv_b, fwd, st);
         if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
-        if (rc != FMX_OK) break;
-        const UpdArgs ua = fill_upd(table, hyper, w, sorted, nullptr, cur->S, cur->dz, cur->dz, nullptr, B, cur->loss, inv_b,
-                                    loss_out ? loss_out + s : nullptr, nullptr, cur->sample_ld, fwd->error);
-        if (s + 1 < n_steps) {
-          const int jn = (s + 1) % n_pool;
-          const FwdArgs fa = fill_fwd(table, hyper, idx_pool + (size_t)jn * B * F, nullptr, y_pool + (size_t)jn * B, B, loss_kind, inv_b, nxt);
-          // debug 6 (tools/fused_stamps.py): the caller's loss buffer is followed by room for the launch's time stamps
-          unsigned long long *stamps = (tune().fused_debug == 6 && loss_out)
-                                           ? reinterpret_cast<unsigned long long *>(loss_out + (((size_t)n_steps + 63) & ~(size_t)63)) : nullptr;
-          rc = fused_impl(table, rule, ua, fa, w, n_fused++, st, stamps);
-        } else {
-          launch_update_pair<4>(ua, rule, false, st);
-          rc = check_launch("k_fm_update");
-        }
+        if (rc == FMX_OK)
+          rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
+                           loss_out ? loss_out + s : nullptr, st, nullptr, fwd->sample_ld, fwd->error);
       }
       if (sd) (void)hipEventRecord(sd->consumed[g & 1], st);
       first_step = next_first;
@@ -3365,408 +2875,6 @@ int fmx_mlp_hedge_fit(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge
   a.mode = MLP_MODE_HEDGE;
   a.inv_b = 1.0f / (float)B;
   return mlp_launch(mlp, a, B, kp, stream, "fmx_mlp_hedge_fit");
-}
-
-// the forward GEMM chain of the mini-batch MLP: acts[l] = relu(acts[l-1] . W_l^T + b_l)
-static void mlp_big_forward(const fmx_mlp_t *mlp, const MlpBigWs &w, const float *bi, int32_t ld_bi, int32_t B, hipStream_t st) {
-  const int L = mlp->n_layers, H = mlp->hidden, k = mlp->k;
-  const size_t act = align_up((size_t)B * H * 4, 256) / 4;
-  long long o = 0;
-  for (int l = 0; l < L; ++l) {
-    const int in = l == 0 ? k : H;
-    GemmArgs g;
-    g.mask = nullptr;
-    g.rowadd = nullptr;
-    g.ldmask = 0;
-    g.c_split_stride = 0;
-    g.zero_cols_to = 0;
-    g.A = l == 0 ? bi : w.acts + (size_t)(l - 1) * act;
-    g.lda = l == 0 ? ld_bi : H;
-    g.Bm = mlp->params + o;
-    g.ldb = in;
-    g.C = w.acts + (size_t)l * act;
-    g.ldc = H;
-    g.bias = mlp->params + o + (long long)H * in;
-    g.M = B;
-    g.N = H;
-    g.K = in;
-    g.k_chunk = in;
-    g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
-    g.b_bytes = (unsigned)((size_t)H * g.ldb * 4);
-    g.vec = (size_t)B * g.lda * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 0, 1);
-    launch_gemm<0, 1, EPI_BIAS_RELU>(g, 1, st);
-    o += (long long)H * in + H;
-  }
-}
-
-int fmx_mlp_forward_batch(const fmx_mlp_t *mlp, const float *bi, int32_t ld_bi, const float *base, int32_t B, void *workspace,
-                          float *logit_out, float *layers_out, fmx_stream_t stream) {
-  if (!mlp || !mlp->params || !bi || !base || !workspace || (!logit_out && !layers_out))
-    return fail(FMX_ERR_ARG, "fmx_mlp_forward_batch: null argument");
-  if (mlp->n_layers < 1 || mlp->n_layers > MLP_BIG_MAX_L || mlp->k < 1 || mlp->hidden < 1 || B < 1)
-    return fail(FMX_ERR_UNSUPPORTED, "fmx_mlp_forward_batch: needs 1 <= layers <= %d, k >= 1, hidden >= 1, B >= 1", MLP_BIG_MAX_L);
-  if (ld_bi < mlp->k) return fail(FMX_ERR_SHAPE, "fmx_mlp_forward_batch: ld_bi smaller than k");
-  if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const MlpBigWs w = mlp_big_carve(mlp, B, workspace);
-  mlp_big_forward(mlp, w, bi, ld_bi, B, st);
-  MlpOutArgs a;
-  a.acts = w.acts;
-  a.act_stride = align_up((size_t)B * mlp->hidden * 4, 256) / 4;
-  a.base = base;
-  a.logit = logit_out;
-  a.layers = layers_out;
-  a.B = B;
-  a.hidden = mlp->hidden;
-  a.n_layers = mlp->n_layers;
-  hipLaunchKernelGGL(k_mlp_outputs, dim3((B + 3) / 4), dim3(256), 0, st, a);
-  return check_launch("fmx_mlp_forward_batch");
-}
-
-int64_t fmx_mlp_section_workspace_bytes(const fmx_mlp_t *mlp, int32_t B) {
-  if (!mlp || mlp->n_layers < 1 || mlp->n_layers > MLP_BIG_MAX_L || mlp->k < 1 || mlp->hidden < 1 || B < 1)
-    return fail(FMX_ERR_ARG, "fmx_mlp_section_workspace_bytes: bad mlp / B");
-  return (int64_t)mlp_big_carve(mlp, B, nullptr).bytes;
-}
-
-// the backward of the mini-batch MLP from dH_{L-1} (already in w.dH): the dgrad chain (with `rowadd_l` [L, B] added to
-// layer l's dH before its mask when given: Hedge), dL/dbi into gbi_out when given, every layer's dW | db in one launch,
-// then the fixed-order reduction into `grads` (+ optional SGD, + the mean of w.loss_b into loss_out when given)
-// skip_dgrad: k_mlp_chain has already produced every dH_l and gbi; only the weight gradients and their reduction remain
-static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const float *bi, int32_t ld_bi, int32_t B,
-                             const float *rowadd_l, float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply,
-                             float *loss_out, float inv_b, hipStream_t st, bool skip_dgrad = false) {
-  const int L = mlp->n_layers, H = mlp->hidden, k = mlp->k;
-  const size_t act = align_up((size_t)B * H * 4, 256) / 4;
-  const float *Wl[MLP_BIG_MAX_L];
-  long long off[MLP_BIG_MAX_L];
-  {
-    long long o = 0;
-    for (int l = 0; l < L; ++l) {
-      const int in = l == 0 ? k : H;
-      off[l] = o;
-      Wl[l] = mlp->params + o;
-      o += (long long)H * in + H;
-    }
-  }
-  auto base_args = [] {
-    GemmArgs g;
-    g.bias = nullptr;
-    g.mask = nullptr;
-    g.rowadd = nullptr;
-    g.ldmask = 0;
-    g.c_split_stride = 0;
-    g.zero_cols_to = 0;
-    return g;
-  };
-  int splits[MLP_BIG_MAX_L] = {0};
-  WgradBatch wb;
-  wb.n = 0;
-  int wgx = 1;
-  for (int l = L - 1; l >= 0; --l) {
-    const int in = l == 0 ? k : H;
-    float *cur = w.dH + (size_t)l * act;
-    const float *prev = l == 0 ? bi : w.acts + (size_t)(l - 1) * act;
-    const int ldprev = l == 0 ? ld_bi : H;
-    {  // dW_l = dH_l^T . H_{l-1}, split over the batch
-      GemmArgs g = base_args();
-      g.A = cur;
-      g.lda = H;
-      g.Bm = prev;
-      g.ldb = ldprev;
-      g.C = w.parts[l];
-      g.ldc = w.ldp[l];
-      g.M = H;
-      g.N = in;
-      g.K = B;
-      // splits of the batch: 16 for a 256 x 256 layer (528 workgroups over the launch), at most B / 128
-      const int tiles = ((in + G_BN - 1) / G_BN) * ((H + G_BM - 1) / G_BM);
-      int n_split = 256 / tiles;  // (192 .. 384: the same within 0.5 us; 128: +6 us, 512 / 1024: +4 us -- tools/mlp_section_times.py)
-      if (n_split > w.n_split) n_split = w.n_split;
-      if (n_split < 1) n_split = 1;
-      g.k_chunk = ((B + n_split - 1) / n_split + G_BK_WGRAD - 1) / G_BK_WGRAD * G_BK_WGRAD;
-      n_split = (B + g.k_chunk - 1) / g.k_chunk;
-      splits[l] = n_split;
-      g.c_split_stride = (long long)H * w.ldp[l];
-      g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
-      g.b_bytes = (unsigned)((size_t)B * g.ldb * 4);
-      g.vec = (size_t)B * (g.lda > g.ldb ? g.lda : g.ldb) * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 1, 0);
-      wb.g[wb.n] = g;                                  // launched together with the other layers' after the dgrad chain
-      wb.z_end[wb.n] = (wb.n ? wb.z_end[wb.n - 1] : 0) + n_split;
-      wb.bias_col[wb.n] = in;
-      if ((in + G_BN - 1) / G_BN > wgx) wgx = (in + G_BN - 1) / G_BN;
-      ++wb.n;
-    }
-    if (skip_dgrad) continue;
-    if (l == 0 && !gbi_out) continue;  // nothing below the first layer wants a gradient (Hedge leaves the tables alone)
-    GemmArgs g = base_args();
-    g.A = cur;
-    g.lda = H;
-    g.Bm = Wl[l];
-    g.ldb = in;
-    g.M = B;
-    g.N = in;
-    g.K = H;
-    g.k_chunk = H;
-    g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
-    g.b_bytes = (unsigned)((size_t)H * g.ldb * 4);
-    g.vec = (size_t)B * g.lda * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 0, 0);
-    if (l > 0) {  // dH_{l-1} = (dH_l . W_l [+ the layer's own output gradient]) * (H_{l-1} > 0)
-      g.C = w.dH + (size_t)(l - 1) * act;
-      g.ldc = H;
-      g.mask = prev;
-      g.ldmask = H;
-      g.rowadd = rowadd_l ? rowadd_l + (size_t)(l - 1) * B : nullptr;
-      launch_gemm<0, 0, EPI_MASK>(g, 1, st);
-    } else {  // dL/dbi through the MLP, padding columns zeroed
-      g.C = gbi_out;
-      g.ldc = ld_gbi;
-      g.zero_cols_to = ld_gbi;
-      launch_gemm<0, 0, EPI_NONE>(g, 1, st);
-    }
-  }
-  {  // ---- every layer's dW_l | db_l in one launch ----
-    static bool raised = false;
-    if (!raised) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)g_lds_bytes(G_BK_WGRAD));
-      raised = true;
-    }
-    // grid x = the GEMM's column tiles + one slice for the bias columns (y there = blocks of 64 columns of dH_l)
-    hipLaunchKernelGGL(k_mlp_wgrad, dim3(wgx + 1, (H + G_BM - 1) / G_BM, wb.z_end[wb.n - 1]), dim3(256), g_lds_bytes(G_BK_WGRAD), st,
-                       wb);
-  }
-  MlpReduceArgs a;
-  long long biggest = 0;
-  for (int l = 0; l < MLP_BIG_MAX_L; ++l) {
-    const int in = l == 0 ? k : H;
-    a.parts[l] = l < L ? w.parts[l] : nullptr;
-    a.out_dim[l] = H;
-    a.in_dim[l] = in;
-    a.ldp[l] = l < L ? w.ldp[l] : 0;
-    a.grad_off[l] = l < L ? off[l] : 0;
-    a.n_split[l] = splits[l];
-    if (l < L && (long long)H * (in + 1) > biggest) biggest = (long long)H * (in + 1);
-  }
-  a.grads = grads;
-  a.params = mlp->params;
-  a.lr = lr_apply;
-  a.n_layers = L;
-  a.loss_b = w.loss_b;
-  a.loss_out = loss_out;
-  a.B = B;
-  a.inv_b = inv_b;
-  const int bx = (int)((biggest + 255) / 256);
-  hipLaunchKernelGGL(k_mlp_reduce, dim3(bx > 256 ? 256 : bx, L), dim3(256), 0, st, a);
-}
-
-static int mlp_big_check(const fmx_mlp_t *mlp, int32_t B, const void *workspace, const char *who) {
-  if (!mlp || !mlp->params || !workspace) return fail(FMX_ERR_ARG, "%s: null argument", who);
-  if (mlp->n_layers < 1 || mlp->n_layers > MLP_BIG_MAX_L || mlp->k < 1 || mlp->hidden < 1 || B < 1)
-    return fail(FMX_ERR_UNSUPPORTED, "%s: needs 1 <= layers <= %d, k >= 1, hidden >= 1, B >= 1", who, MLP_BIG_MAX_L);
-  if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
-  return FMX_OK;
-}
-
-int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, int32_t ld_bi, const float *base,
-                    const float *y, int32_t B, float inv_b, void *workspace, float *logit_out, float *dz_out,
-                    float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply, float *loss_out, fmx_stream_t stream) {
-  if (int rc = mlp_big_check(mlp, B, workspace, "fmx_mlp_section")) return rc;
-  if (!bi || !base || !y || !dz_out || !gbi_out || !grads) return fail(FMX_ERR_ARG, "fmx_mlp_section: null argument");
-  if (ld_bi < mlp->k || ld_gbi < mlp->k) return fail(FMX_ERR_SHAPE, "fmx_mlp_section: ld_bi / ld_gbi smaller than k");
-  if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "fmx_mlp_section needs a loss");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const MlpBigWs w = mlp_big_carve(mlp, B, workspace);
-  const int L = mlp->n_layers, H = mlp->hidden;
-  const size_t act = align_up((size_t)B * H * 4, 256) / 4;
-  if (tune().mlp_chain && chain_eligible(mlp)) {
-    // forward, loss and the dgrad chain in ONE launch (k_mlp_chain), then the weight gradients and their reduction
-    ChainArgs c;
-    c.params = mlp->params;
-    c.bi = bi;
-    c.base = base;
-    c.y = y;
-    c.acts = w.acts;
-    c.dH = w.dH;
-    c.act_stride = act;
-    c.logit_out = logit_out;
-    c.dz_out = dz_out;
-    c.loss_b = w.loss_b;
-    c.gbi_out = gbi_out;
-    long long o = 0;
-    for (int l = 0; l < L; ++l) {
-      const int in = l == 0 ? mlp->k : H;
-      c.w_off[l] = o;
-      c.b_off[l] = o + (long long)H * in;
-      o += (long long)H * in + H;
-    }
-    c.B = B;
-    c.k = mlp->k;
-    c.H = H;
-    c.L = L;
-    c.ld_bi = ld_bi;
-    c.ld_gbi = ld_gbi;
-    c.loss_kind = loss_kind;
-    c.inv_b = inv_b;
-    c.stamps = tune().mlp_chain == 2 ? reinterpret_cast<unsigned long long *>(w.loss_lb) : nullptr;  // debug: tools/mlp_chain_stamps.py
-    static bool raised = false;
-    if (!raised) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)chain_lds_bytes(CH_MAXH));
-      raised = true;
-    }
-    hipLaunchKernelGGL(k_mlp_chain, dim3((B + CH_R - 1) / CH_R), dim3(256 + CH_LT), chain_lds_bytes(H), st, c);
-    mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st, true);
-    return check_launch("fmx_mlp_section (k_mlp_chain)");
-  }
-  mlp_big_forward(mlp, w, bi, ld_bi, B, st);
-  {  // ---- loss, dL/dlogit, dH_L ----
-    MlpLossArgs a;
-    a.H = w.acts + (size_t)(L - 1) * act;
-    a.dH = w.dH + (size_t)(L - 1) * act;
-    a.base = base;
-    a.y = y;
-    a.out = logit_out;
-    a.dz = dz_out;
-    a.loss_b = w.loss_b;
-    a.B = B;
-    a.hidden = H;
-    a.ldh = H;
-    a.loss_kind = loss_kind;
-    a.inv_b = inv_b;
-    hipLaunchKernelGGL(k_mlp_loss, dim3((B + 3) / 4), dim3(256), 0, st, a);
-  }
-  mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st);
-  return check_launch("fmx_mlp_section");
-}
-
-int fmx_mlp_hedge_section(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge_s, float *alpha, const float *bi,
-                          int32_t ld_bi, const float *base, const float *y, int32_t B, void *workspace, float *grads,
-                          float *losses_out, fmx_stream_t stream) {
-  if (int rc = mlp_big_check(mlp, B, workspace, "fmx_mlp_hedge_section")) return rc;
-  if (!alpha || !bi || !base || !y || !grads) return fail(FMX_ERR_ARG, "fmx_mlp_hedge_section: null argument");
-  if (ld_bi < mlp->k) return fail(FMX_ERR_SHAPE, "fmx_mlp_hedge_section: ld_bi smaller than k");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const MlpBigWs w = mlp_big_carve(mlp, B, workspace);
-  const int L = mlp->n_layers, H = mlp->hidden;
-  const size_t act = align_up((size_t)B * H * 4, 256) / 4;
-  const float inv_b = 1.0f / (float)B;  // nn.BCELoss: the mean over the batch
-  mlp_big_forward(mlp, w, bi, ld_bi, B, st);
-  {
-    MlpHedgeLossArgs a;
-    a.acts = w.acts;
-    a.act_stride = act;
-    a.dH_top = w.dH + (size_t)(L - 1) * act;
-    a.base = base;
-    a.y = y;
-    a.alpha = alpha;
-    a.dzl = w.dzl;
-    a.loss_lb = w.loss_lb;
-    a.B = B;
-    a.hidden = H;
-    a.n_layers = L;
-    a.inv_b = inv_b;
-    hipLaunchKernelGGL(k_mlp_hedge_loss, dim3((B + 3) / 4), dim3(256), 0, st, a);
-  }
-  // hidden layers: theta -= lr * sum_i alpha_i d loss_i / d theta (one backward pass: d loss_i / d layer_j = 0 for j > i)
-  mlp_big_backward(mlp, w, bi, ld_bi, B, w.dzl, nullptr, 0, grads, lr, nullptr, inv_b, st);
-  {
-    MlpHedgeAlphaArgs a;
-    a.loss_lb = w.loss_lb;
-    a.alpha = alpha;
-    a.losses_out = losses_out;
-    a.B = B;
-    a.n_layers = L;
-    a.inv_b = inv_b;
-    a.hedge_b = hedge_b;
-    a.hedge_s = hedge_s;
-    hipLaunchKernelGGL(k_mlp_hedge_alpha, dim3(1), dim3(256), 0, st, a);
-  }
-  return check_launch("fmx_mlp_hedge_section");
-}
-
-int fmx_sftrl_run(const double *X, const double *y, int32_t N, int32_t D, int32_t d, int32_t m, double eta, double thres,
-                  int32_t task, double *BP, double *BN, int32_t *counts, double *w, double *g_w, double *pred_out,
-                  int32_t *status, fmx_stream_t stream) {
-  if (!X || !y || !BP || !BN || !counts || !pred_out || !status) return fail(FMX_ERR_ARG, "fmx_sftrl_run: null argument");
-  if ((w == nullptr) != (g_w == nullptr)) return fail(FMX_ERR_ARG, "fmx_sftrl_run: w and g_w go together");
-  if (N < 0 || D < 1 || d < 1 || d > D || m < 1) return fail(FMX_ERR_ARG, "fmx_sftrl_run: bad sizes");
-  if (task != 0 && task != 1) return fail(FMX_ERR_ARG, "fmx_sftrl_run: task must be 0 (cls) or 1 (reg)");
-  if (d > SF_MAX_D || 2 * m > SF_MAX_C || D > 64)
-    return fail(FMX_ERR_UNSUPPORTED, "fmx_sftrl_run: needs sketch dim <= %d, 2 m <= %d, features <= 64 (got %d, %d, %d)", SF_MAX_D,
-                SF_MAX_C, d, 2 * m, D);
-  if (N == 0) return FMX_OK;
-  SftrlArgs a;
-  a.X = X;
-  a.y = y;
-  a.BP = BP;
-  a.BN = BN;
-  a.counts = counts;
-  a.w = w;
-  a.g_w = g_w;
-  a.pred = pred_out;
-  a.status = status;
-  a.eta = eta;
-  a.thres = thres;
-  a.N = N;
-  a.D = D;
-  a.d = d;
-  a.m = m;
-  a.cls = task == 0;
-  a.ms = nullptr;
-  a.etas = nullptr;
-  a.B_stride = a.w_stride = a.pred_stride = 0;
-  const size_t lds = ((size_t)2 * d * 2 * m + 2 * (size_t)d * d + d + 48 + D) * sizeof(double) + (size_t)d * sizeof(int) + 16;
-  static bool raised = false;
-  if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sftrl_online), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    raised = true;
-  }
-  hipLaunchKernelGGL(k_sftrl_online, dim3(1), dim3(64), lds, static_cast<hipStream_t>(stream), a);
-  return check_launch("k_sftrl_online");
-}
-
-int fmx_sftrl_grid(const double *X, const double *y, int32_t N, int32_t D, int32_t d, int32_t n_settings, const int32_t *ms,
-                   const double *etas, int32_t m_max, double thres, int32_t task, double *BP, double *BN, int32_t *counts, double *w,
-                   double *g_w, double *pred_out, int32_t *status, fmx_stream_t stream) {
-  if (!X || !y || !ms || !etas || !BP || !BN || !counts || !pred_out || !status) return fail(FMX_ERR_ARG, "fmx_sftrl_grid: null argument");
-  if ((w == nullptr) != (g_w == nullptr)) return fail(FMX_ERR_ARG, "fmx_sftrl_grid: w and g_w go together");
-  if (N < 0 || D < 1 || d < 1 || d > D || m_max < 1 || n_settings < 0) return fail(FMX_ERR_ARG, "fmx_sftrl_grid: bad sizes");
-  if (task != 0 && task != 1) return fail(FMX_ERR_ARG, "fmx_sftrl_grid: task must be 0 (cls) or 1 (reg)");
-  if (d > SF_MAX_D || 2 * m_max > SF_MAX_C || D > 64)
-    return fail(FMX_ERR_UNSUPPORTED, "fmx_sftrl_grid: needs sketch dim <= %d, 2 m <= %d, features <= 64 (got %d, %d, %d)", SF_MAX_D,
-                SF_MAX_C, d, 2 * m_max, D);
-  if (N == 0 || n_settings == 0) return FMX_OK;
-  SftrlArgs a;
-  a.X = X;
-  a.y = y;
-  a.BP = BP;
-  a.BN = BN;
-  a.counts = counts;
-  a.w = w;
-  a.g_w = g_w;
-  a.pred = pred_out;
-  a.status = status;
-  a.eta = 0.0;
-  a.thres = thres;
-  a.N = N;
-  a.D = D;
-  a.d = d;
-  a.m = m_max;
-  a.cls = task == 0;
-  a.ms = ms;
-  a.etas = etas;
-  a.B_stride = (long long)d * 2 * m_max;
-  a.w_stride = D;
-  a.pred_stride = N;
-  const size_t lds = ((size_t)2 * d * 2 * m_max + 2 * (size_t)d * d + d + 48 + D) * sizeof(double) + (size_t)d * sizeof(int) + 16;
-  static bool raised = false;
-  if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sftrl_online), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    raised = true;
-  }
-  hipLaunchKernelGGL(k_sftrl_online, dim3(n_settings), dim3(64), lds, static_cast<hipStream_t>(stream), a);
-  return check_launch("k_sftrl_online (grid)");
 }
 
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream) {

@@ -40,8 +40,8 @@ def _ptr(t):
 
 
 class HandOffTimeout(RuntimeError):
-    """Device error word 2 (k_fm_update: a crossing run's row update was skipped) or 3 (k_fm_fused: the forward may have read
-    stale rows): an in-launch hand-off ran into its spin bound.  Never observed; the table must be considered corrupt."""
+    """Device error word 2 (k_fm_update: a crossing run's row update was skipped): an in-launch hand-off ran into its spin
+    bound.  Never observed; the table must be considered corrupt."""
 
     def __init__(self, code):
         super().__init__(f"fmx: in-launch hand-off timed out (device error word {code}); the table is not the exact result")
@@ -301,7 +301,7 @@ class FMEngine:
         return self._mlp_loss, self._mlp_dz, self._mlp_gbi
 
     def check_error_flag(self):
-        """The device-side error word (include/fmx.h, Conventions): 1 -> IndexError like nn.Embedding; 2 / 3 -> HandOffTimeout
+        """The device-side error word (include/fmx.h, Conventions): 1 -> IndexError like nn.Embedding; 2 -> HandOffTimeout
         (an in-launch hand-off ran into its spin bound: the table is no longer the exact result).  Synchronises."""
         code = int(self.error.item())
         if code != 0:

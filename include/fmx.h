@@ -25,9 +25,8 @@
  *     the mutable process state is (a)-(c) above plus the thread-local error string;
  *   - device-side conditions are reported through the caller's int32 error word (fmx_fwd_out_t.error and the `error`
  *     arguments): 1 = an index outside its field (that row is treated as absent), 2 = an in-launch hand-off of the update ran
- *     into its spin bound (the row update of that run was SKIPPED: the table is no longer the exact result), 3 = the
- *     forward workgroups of the fused step launch ran into theirs (the forward read rows that may be stale).  2 and 3 mean
- *     a resident-grid assumption was violated; they have never been observed and are there so that a fault ends in a
+ *     into its spin bound (the row update of that run was SKIPPED: the table is no longer the exact result).  2 means
+ *     a dispatch-order assumption was violated; it has never been observed and is there so that a fault ends in a
  *     flag, not in a hang.
  *
  * Table layout in HBM (one flat buffer for all fields; field f owns rows [field_offsets[f], field_offsets[f+1])):
@@ -138,11 +137,8 @@ const char *fmx_last_error_string(void);
  *   "sort_ahead"   (default 8)  most batches sorted per side-stream launch in fmx_fm_stream (1..8).
  *   "sort_chunked" (default 1)  0: one workgroup per field at every width; 1: k_sort_chunk + k_sort_merge (1,024-composite
  *                                chunks spread over the chip, stable rank merge) from 8,192 composites per field on; 2: from 2,048 on.
- *   "fused_step"   (default 0)  1 / 2: fmx_fm_stream launches update(s) + forward(s + 1) as ONE launch (k_fm_fused; 1: one
- *                                agent-scope acquire per forward workgroup and plain gather loads, 2: sc1 gather loads).
  *   "mlp_chain"    (default 1)  0: fmx_mlp_section as separate GEMM launches instead of k_mlp_chain (forward + loss + dgrad chain
  *                                in one launch); same results up to summation order.
- *   "sort_prefetch" (default 0) 1: the occurrence sort also touches the rows of its batch (measured slower).
  *   "online_persistent" (default 1)  0: fmx_online_run_mlp as per-sample launches instead of one workgroup walking the stream. */
 int fmx_set_option(const char *name, int value);
 
@@ -158,8 +154,6 @@ int fmx_sorted_bbits(int B);
  *   meta    int32  [F, Bp/64, 2]     per 64-entry tile: does a run come in from / go out to the neighbouring tile; with the
  *                                    in-launch hand-off word 0 is (launch sequence << 4 | states) and is polled by later tiles
  *   parts   float  [F, Bp/64, 2, 2*kp+4]  partial sums of the runs that cross a tile boundary
- *   done    uint32 [16][32]          arrival counters of the fused step launch;  fwd2 float [B, kp] + 2 [B]: its second set of
- *                                    forward outputs (S, dz, loss ping-pong between the caller's buffers and these)
  * The workspace must be ZERO-FILLED once before its first use (the hand-off's flag words are compared with a
  * non-zero launch sequence number; never-written words must not match one by accident).
  * Negative on a bad table. */

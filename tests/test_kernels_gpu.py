@@ -412,40 +412,6 @@ def test_stream_matches_repeated_steps(fmx):
         np.testing.assert_array_equal(np.asarray(losses1, dtype=np.float32), loss_out.cpu().numpy())
 
 
-@pytest.mark.parametrize("rule,zipf,n_steps", [("ftrl", False, 41), ("ftrl", True, 16), ("sgd", False, 9), ("signadam", True, 2)])
-def test_fused_step_launch_equals_separate_launches(fmx, rule, zipf, n_steps):
-    """fmx_fm_stream's steady state is ONE launch per step: update(s) + forward(s + 1) (k_fm_fused), the updated rows handed to
-    the next batch's forward waves inside the launch (write-through stores, sc1 loads, arrival counters).  With
-    fmx_set_option("fused_step", 0) the same loop launches forward and update separately.  Same arithmetic, so the tables,
-    the losses and the last step's forward outputs must be IDENTICAL BITS at the BASELINE size (Criteo vocabulary, k = 16,
-    B = 4096), where every sample shares hot rows with the batch before it."""
-    lib = fmx._lib.load()
-    sizes, k, B, n_pool = CRITEO_SIZES, 16, 4096, 5
-    prs = [make_problem(sizes, k, B, seed=900 + j, zipf=zipf) for j in range(n_pool)]
-    idx_pool = torch.from_numpy(np.stack([p["idx"] for p in prs])).cuda()
-    y_pool = torch.from_numpy(np.stack([p["y"] for p in prs])).cuda()
-    hyp = fmx.Hyper(**HYP)
-    res = []
-    for fused in (1, 0):
-        if rule == "ftrl":
-            t = ftrl_table(fmx, sizes, k, ftrl_state(prs[0], HYP))
-        else:
-            t = weights_table(fmx, sizes, k, prs[0])
-        eng = fmx.FMEngine(t, max_batch=B)
-        loss_out = torch.zeros(n_steps, device="cuda")
-        old = lib.fmx_set_option(b"fused_step", fused)
-        try:
-            eng.stream(hyp, rule, "logits", idx_pool, y_pool, n_steps, loss_out)
-            torch.cuda.synchronize()
-        finally:
-            lib.fmx_set_option(b"fused_step", old)
-        eng.check_error_flag()
-        res.append((t.rows.cpu().numpy(), t.bias.cpu().numpy(), loss_out.cpu().numpy(), eng.S[:B].cpu().numpy(), eng.dz[:B].cpu().numpy()))
-    for a, b, what in zip(res[0], res[1], ("rows", "bias", "losses", "S of the last step", "dz of the last step")):
-        np.testing.assert_array_equal(a, b, err_msg=what)
-    assert np.isfinite(res[0][2]).all() and (res[0][2] > 0).all()
-
-
 @pytest.mark.parametrize("rule,real_x", [("ftrl", False), ("sgd", True)])
 def test_split_sort_fields_equal_whole_fields(fmx, rule, real_x):
     """Large fields cut into sort pieces (fmx_table_t.sort_offsets; needed when (index, sample) would not fit 32 bits) are
