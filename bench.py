@@ -354,7 +354,7 @@ def main():
     idx_np, y_np = synth_pool(N_POOL, BATCH, CRITEO_SIZES, SEED + 1000 * rank, zipf=args.zipf)
     idx_pool = torch.from_numpy(idx_np).to(dev)
     y_pool = torch.from_numpy(y_np).to(dev)
-    loss_buf = torch.zeros(max(args.steps, args.warmup, 1), device=dev)
+    loss_buf = torch.zeros(max(args.steps, args.warmup, 100), device=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -369,10 +369,15 @@ def main():
         stream_gbps = stream_read_probe(fmx, torch, dev)
     if world == 1:
         # ---- one GPU: the online loop of fmx_fm_stream over the resident pool.  Warm-up, then EXACTLY K timed steps ----
-        eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.warmup, loss_buf)
+        # the loop runs on a stream of its own (the legacy default stream is slow to enqueue on) through a prepared call: the
+        # structs, pointers and the stream handle are bound once, a call is one foreign call (FMEngine.prepare_stream)
+        work = torch.cuda.Stream(device=dev)
+        barrier()
+        run_loop = eng.prepare_stream(hyper, RULE, "logits", idx_pool, y_pool, loss_buf, stream=work)
+        run_loop(args.warmup)
         barrier()
         t0 = time.perf_counter()
-        eng.stream(hyper, RULE, "logits", idx_pool, y_pool, args.steps, loss_buf)
+        run_loop(args.steps)
         barrier()
         dt = time.perf_counter() - t0
         eng.check_error_flag()
@@ -384,7 +389,7 @@ def main():
             for _ in range(5):
                 barrier()
                 tc = time.perf_counter()
-                eng.stream(hyper, RULE, "logits", idx_pool, y_pool, 20, loss_buf)
+                run_loop(20)
                 barrier()
                 ts.append(time.perf_counter() - tc)
             short_run = {"steps_per_call": 20, "calls": 5, "median_ms_per_step": float(np.median(ts)) / 20 * 1e3,
@@ -394,7 +399,7 @@ def main():
         for _ in range(20 if args.steps >= 200 and not args.loop_only else 0):
             barrier()
             tc = time.perf_counter()
-            eng.stream(hyper, RULE, "logits", idx_pool, y_pool, 100, loss_buf)
+            run_loop(100)
             barrier()
             chunk_us.append((time.perf_counter() - tc) / 100 * 1e6)
         # the measuring pass (fmx.h, fmx_fm_stream with kernel_ms): groups of 8 steps -- one sort launch, the 8 forwards

@@ -47,299 +47,7 @@ int check_launch(const char *what) {
 
 namespace {
 
-// ------------------------------------------------------------------------------------------------------------
-// k_sort_occ
-// ------------------------------------------------------------------------------------------------------------
-struct SortArgs {
-  // one launch may sort several batches of a pool: workgroup (f, j) sorts field f of batch (pool_first + j) % n_pool into
-  // sorted + j * sorted_stride (n_batches == 1 and pool_stride == 0 for a single batch)
-  int32_t n_pool, pool_first, n_batches;
-  int64_t pool_stride, sorted_stride;  // in elements
-  const int32_t *idx;
-  const int64_t *foff;   // the fields' row offsets (range check of an index against its field)
-  const int64_t *soff;   // the SORT fields' row offsets: a refinement of foff (fmx_table_t.sort_offsets), or foff itself
-  const int32_t *cols;   // the field (idx column) every sort field is a piece of, or null (sort field == field)
-  uint32_t *sorted;
-  int32_t *error;
-  int32_t B, F, Bp, bbits;  // F: number of SORT fields
-  int32_t Fi;               // number of fields = columns of idx
-};
-
-// Bitonic network on N = Bp composites held E per thread in a blocked layout (element i = tid * E + r):
-//   partner distance j <  E        in-thread compare-exchange
-//   E <= j < 64 E                  partner in another lane of the wave: xor_lane<j / E>
-//   j >= 64 E                      partner in another wave: through LDS
-template <int E, int LJ>
-__device__ __forceinline__ void bitonic_lane_stage(uint32_t (&v)[E], int i0, int lane, int k) {
-  const bool lower = (lane & LJ) == 0;
-  const bool up = (i0 & k) == 0;  // (i & k) is the same for all r because k > j >= E
-  const bool take_min = lower == up;
-#pragma unroll
-  for (int r = 0; r < E; ++r) {
-    const uint32_t o = xor_lane<LJ>(v[r], lane);
-    const uint32_t lo = v[r] < o ? v[r] : o, hi = v[r] < o ? o : v[r];
-    v[r] = take_min ? lo : hi;
-  }
-}
-
-template <int E>
-__device__ __forceinline__ void bitonic_local(uint32_t (&v)[E], int tid, int k, int jmax) {
-  // stages j = jmax, jmax/2, ..., 1 of merge level k, all of which stay inside one wave
-  const int i0 = tid * E;
-  const int lane = tid & 63;
-  if (jmax >= 32 * E) bitonic_lane_stage<E, 32>(v, i0, lane, k);
-  if (jmax >= 16 * E) bitonic_lane_stage<E, 16>(v, i0, lane, k);
-  if (jmax >= 8 * E) bitonic_lane_stage<E, 8>(v, i0, lane, k);
-  if (jmax >= 4 * E) bitonic_lane_stage<E, 4>(v, i0, lane, k);
-  if (jmax >= 2 * E) bitonic_lane_stage<E, 2>(v, i0, lane, k);
-  if (jmax >= E) bitonic_lane_stage<E, 1>(v, i0, lane, k);
-#pragma unroll
-  for (int j = E / 2; j > 0; j >>= 1) {
-    if (j <= jmax) {
-#pragma unroll
-      for (int r = 0; r < E; ++r) {
-        if ((r & j) == 0) {
-          const bool up = ((i0 + r) & k) == 0;
-          const uint32_t x = v[r], y = v[r + j];
-          if ((x > y) == up) { v[r] = y; v[r + j] = x; }
-        }
-      }
-    }
-  }
-}
-
-// composites of samples i0 .. i0 + E - 1 of field f: every index load is issued before the first is used (a branch per
-// element -- range check, error flag -- made the compiler wait for each load in turn: E dependent HBM round trips)
-// Sort field f is rows [soff[f], soff[f + 1]) of field col: an index outside that piece belongs to another piece of the
-// field (padding here, no error); an index outside the FIELD raises the flag.
-template <int E>
-__device__ __forceinline__ void load_composites(const SortArgs &a, int f, int i0, uint32_t (&v)[E]) {
-  const int col = a.cols ? a.cols[f] : f;
-  const int64_t f_lo = a.foff[col];
-  const uint32_t field_rows = (uint32_t)(a.foff[col + 1] - f_lo);
-  const uint32_t base = (uint32_t)(a.soff[f] - f_lo), piece_rows = (uint32_t)(a.soff[f + 1] - a.soff[f]);
-  uint32_t li[E];
-#pragma unroll
-  for (int r = 0; r < E; ++r) {
-    const int i = i0 + r;
-    li[r] = (uint32_t)a.idx[(size_t)(i < a.B ? i : a.B - 1) * a.Fi + col];
-  }
-  bool bad = false;
-#pragma unroll
-  for (int r = 0; r < E; ++r) {
-    const int i = i0 + r;
-    const uint32_t lp = li[r] - base;  // wraps to a huge value below the piece
-    const bool mine = i < a.B && lp < piece_rows;
-    v[r] = mine ? ((lp << a.bbits) | (uint32_t)i) : SENT;
-    bad = bad || (i < a.B && li[r] >= field_rows);
-  }
-  if (bad && a.error) *a.error = 1;
-}
-
-// Device body of the occurrence sort of ONE field (the calling workgroup: nt threads, nt * E == Bp): the full bitonic
-// network, stages with partner distance < 64 E in registers / DPP, the cross-wave stages through LDS (Bp words); 78
-// dependent stages at Bp = 4096.  (Tried and removed: every wave sorting its 64 E composites in registers followed by
-// binary-search merge rounds in LDS -- 36 stages + 4 rounds, but LDS-bandwidth bound: 31 us against 22.)
-template <int E>
-__device__ __forceinline__ void sort_field(const SortArgs &a, int f, uint32_t *sm) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  uint32_t v[E];
-  load_composites<E>(a, f, tid * E, v);
-  const int wave_span = 64 * E;  // elements held by one wave
-  uint32_t *dst = a.sorted + (size_t)f * a.Bp;
-  const int half = a.Bp >> 1;
-  for (int k = 2; k <= a.Bp; k <<= 1) {
-    int j = k >> 1;
-    if (j >= wave_span) {
-      // cross-wave stages through LDS
-#pragma unroll
-      for (int r = 0; r < E; ++r) sm[tid * E + r] = v[r];
-      __syncthreads();
-      for (; j >= wave_span; j >>= 1) {
-        for (int t = tid; t < half; t += nt) {
-          const int i = 2 * t - (t & (j - 1));
-          const int l = i + j;
-          const uint32_t x = sm[i], y = sm[l];
-          const bool up = (i & k) == 0;
-          if ((x > y) == up) { sm[i] = y; sm[l] = x; }
-        }
-        __syncthreads();
-      }
-#pragma unroll
-      for (int r = 0; r < E; ++r) v[r] = sm[tid * E + r];
-      __syncthreads();
-    }
-    bitonic_local<E>(v, tid, k, j);
-  }
-#pragma unroll
-  for (int r = 0; r < E; ++r) dst[(size_t)tid * E + r] = v[r];
-}
-
-// (unit, inner) of this block: units are spread round-robin over the 8 XCDs, the `n_inner` blocks of a unit share one
-// (blocks b and b + 8 share an XCD and its L2; placement is for speed only)
-__device__ __forceinline__ bool xcd_unit(int n_units, int n_inner, int &unit, int &inner) {
-  const int b = blockIdx.x, x = b & 7, s = b >> 3;
-  inner = s % n_inner;
-  unit = (s / n_inner) * 8 + x;
-  return unit < n_units;
-}
-
-// Grid (launches of 8 or more batches): 8 * F * ceil(n_batches / 8) workgroups; the F workgroups of one batch sit on ONE XCD: each of them reads one
-// column of the batch's [B, Fi] index slab, i.e. 4 bytes of every 128-byte line, so a slab whose workgroups were dealt over
-// all eight XCDs was fetched from HBM by every one of them (21 MB per 8 batches against 5 MB of indices).
-template <int E>
-__global__ __launch_bounds__(1024) void k_sort_occ(SortArgs a) {
-  extern __shared__ uint32_t sm[];
-  int j, f;  // batch slot of this launch, sort field
-  if (a.n_batches >= 8) {
-    if (!xcd_unit(a.n_batches, a.F, j, f)) return;
-  } else {  // few batches: all their workgroups on one or a few XCDs would leave most of the chip idle (39 workgroups on 32 CUs)
-    j = blockIdx.x / a.F;
-    f = blockIdx.x - j * a.F;
-  }
-  if (j > 0 || a.pool_stride != 0) {
-    a.idx += (size_t)((a.pool_first + j) % a.n_pool) * a.pool_stride;
-    a.sorted += (size_t)j * a.sorted_stride;
-  }
-  sort_field<E>(a, f, sm);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// k_sort_chunk + k_sort_merge: the occurrence sort for Bp >= 2 * SORT_CHUNK, spread over the chip
-// ------------------------------------------------------------------------------------------------------------
-// One workgroup per field keeps a 4,096-composite sort on ONE CU: 78 dependent bitonic stages, VALU-issue bound there
-// (22 us per batch while 217 CUs idle).  Here a field's Bp composites are cut into chunks of SORT_CHUNK = 1,024:
-//   k_sort_chunk  workgroup (field, chunk, batch): 256 threads x 4 composites, the bitonic network on 1,024 (55 stages,
-//                 3 of them through LDS) -> `runs` [F, Bp], every chunk sorted;
-//   k_sort_merge  workgroup (field, chunk, batch): the field's C sorted chunks in LDS (Bp words, 16-byte loads); every
-//                 composite of chunk c finds its rank among the other chunks by binary search (stable: ties -- only the
-//                 0xFFFFFFFF padding ties -- count for earlier chunks, not for later ones) and is stored at
-//                 sorted[f][own index + sum of ranks].
-// The result is the same array the one-workgroup sort produces (composites are unique, so any correct sort gives the
-// same bits).  Block -> work mapping is XCD-aware (blocks b and b + 8 share an XCD and its L2): the F workgroups that
-// read one chunk's [1024, F] slab of idx (each 128-byte line of it holds 32 of a sample's 39 indices and is read by
-// the workgroups of 32 fields) sit on ONE XCD, so the slab is fetched from HBM once instead of once per XCD; likewise
-// the C merge workgroups of a field read the same Bp words.  Placement is for speed only.
-constexpr int SORT_CHUNK = 1024, SORT_CHUNK_E = 4, SORT_CHUNK_THREADS = SORT_CHUNK / SORT_CHUNK_E;
-// from this width on the chunked form is the faster one for ONE batch per launch (MI355X, Criteo vocabulary: 4,096: 17.5 vs
-// 18.5 us; 8,192: 24 vs 36; 16,384: 60 vs 74; 32,768 x 6 fields: 58 us) -- launches of 8 batches: 29 vs 27, 71 vs 55, 294 vs 118
-constexpr int SORT_CHUNKED_MIN_WIDTH = 8192;
-
-struct ChunkArgs {
-  SortArgs s;          // s.sorted: the final lists; runs: the chunk-sorted intermediate, same shape
-  uint32_t *runs;
-  int64_t runs_stride; // elements between the batches of one launch
-  int32_t C;           // chunks per field = Bp / SORT_CHUNK
-};
-
-__global__ __launch_bounds__(SORT_CHUNK_THREADS) void k_sort_chunk(ChunkArgs a) {
-  constexpr int E = SORT_CHUNK_E;
-  __shared__ uint32_t sm[SORT_CHUNK];
-  int unit, f;
-  if (!xcd_unit(a.s.n_batches * a.C, a.s.F, unit, f)) return;
-  const int j = unit / a.C, c = unit - j * a.C;
-  const int32_t *idx = a.s.idx + (size_t)((a.s.pool_first + j) % a.s.n_pool) * a.s.pool_stride;
-  uint32_t *dst = a.runs + (size_t)j * a.runs_stride + (size_t)f * a.s.Bp + (size_t)c * SORT_CHUNK;
-  const int tid = threadIdx.x;
-  uint32_t v[E];
-  {
-    SortArgs sa = a.s;
-    sa.idx = idx;
-    load_composites<E>(sa, f, c * SORT_CHUNK + tid * E, v);
-  }
-  constexpr int wave_span = 64 * E;
-  for (int k = 2; k <= SORT_CHUNK; k <<= 1) {
-    int jj = k >> 1;
-    if (jj >= wave_span) {  // partner in another wave: through LDS
-#pragma unroll
-      for (int r = 0; r < E; ++r) sm[tid * E + r] = v[r];
-      __syncthreads();
-      for (; jj >= wave_span; jj >>= 1) {
-        for (int t = tid; t < SORT_CHUNK / 2; t += SORT_CHUNK_THREADS) {
-          const int i = 2 * t - (t & (jj - 1));
-          const int l = i + jj;
-          const uint32_t x = sm[i], y = sm[l];
-          const bool up = (i & k) == 0;
-          if ((x > y) == up) { sm[i] = y; sm[l] = x; }
-        }
-        __syncthreads();
-      }
-#pragma unroll
-      for (int r = 0; r < E; ++r) v[r] = sm[tid * E + r];
-      __syncthreads();
-    }
-    bitonic_local<E>(v, tid, k, jj);
-  }
-  *reinterpret_cast<uint4 *>(dst + tid * E) = uint4{v[0], v[1], v[2], v[3]};
-}
-
-__global__ __launch_bounds__(SORT_CHUNK_THREADS) void k_sort_merge(ChunkArgs a) {
-  constexpr int E = SORT_CHUNK_E;
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // the field's C sorted chunks: Bp words
-  int unit, c;
-  if (!xcd_unit(a.s.n_batches * a.s.F, a.C, unit, c)) return;
-  const int j = unit / a.s.F, f = unit - j * a.s.F;
-  const uint32_t *src = a.runs + (size_t)j * a.runs_stride + (size_t)f * a.s.Bp;
-  uint32_t *dst = a.s.sorted + (size_t)j * a.s.sorted_stride + (size_t)f * a.s.Bp;
-  const int tid = threadIdx.x;
-  // LDS image: element i of the field at word i + (i >> 5).  A binary search reads the odd multiples of 1024 / 2^d at
-  // depth d; unpadded, all of them fall into one or two of the 32 banks (up to 32-way conflicts, 8x the time over the 11
-  // steps: 13 us per launch); one pad word per 32 spreads every depth over the banks (at most 2-way).
-  auto at = [](int i) { return i + (i >> 5); };
-  {
-    uint4 t[8];  // up to Bp = 8 * 1024: every global load in flight before the first LDS store
-    const int n_it = a.s.Bp / (SORT_CHUNK_THREADS * 4);
-    for (int it0 = 0; it0 < n_it; it0 += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (it0 + u < n_it) t[u] = *reinterpret_cast<const uint4 *>(src + (it0 + u) * SORT_CHUNK_THREADS * 4 + tid * 4);
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (it0 + u < n_it) {
-          const int i = (it0 + u) * SORT_CHUNK_THREADS * 4 + tid * 4;  // i .. i + 3 share i >> 5
-          uint32_t *d4 = smem + at(i);
-          d4[0] = t[u].x; d4[1] = t[u].y; d4[2] = t[u].z; d4[3] = t[u].w;
-        }
-    }
-  }
-  __syncthreads();
-  uint32_t v[E];
-  int pos[E];
-#pragma unroll
-  for (int r = 0; r < E; ++r) {
-    v[r] = smem[at(c * SORT_CHUNK + tid * E + r)];
-    pos[r] = tid * E + r;
-  }
-  for (int o = 0; o < a.C; ++o) {
-    if (o == c) continue;  // workgroup-uniform
-    const uint32_t *run = smem + at(o * SORT_CHUNK);  // SORT_CHUNK is a multiple of 32: run[at(m)] is element m of the run
-    const bool before = o < c;  // ties: an equal composite of an earlier chunk goes first (stable)
-    // number of the run's composites that go before v[r] (ties: an equal composite of an EARLIER chunk goes first; only
-    // the 0xFFFFFFFF padding ties): fixed-step binary searches without branches -- a short-circuit in the comparison
-    // compiled to a branch and a wait per LDS read, 132 dependent reads per thread -- the E searches of a thread
-    // interleaved, so each step has E reads in flight
-    int cnt[E];
-#pragma unroll
-    for (int r = 0; r < E; ++r) cnt[r] = 0;
-#pragma unroll
-    for (int step = SORT_CHUNK / 2; step >= 1; step >>= 1) {
-#pragma unroll
-      for (int r = 0; r < E; ++r) {
-        const uint32_t m = run[at(cnt[r] + step - 1)];
-        const int goes_before = (int)(m < v[r]) | ((int)before & (int)(m == v[r]));
-        cnt[r] += goes_before ? step : 0;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < E; ++r) {  // cnt <= SORT_CHUNK - 1 here: one more comparison for the last element
-      const uint32_t m = run[at(cnt[r])];
-      cnt[r] += (int)(m < v[r]) | ((int)before & (int)(m == v[r]));
-      pos[r] += cnt[r];
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < E; ++r) dst[pos[r]] = v[r];
-}
+#include "fmx_sort.inc"
 
 // ------------------------------------------------------------------------------------------------------------
 // k_fm_forward
@@ -2549,15 +2257,7 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     for (int g = 0; first_step < n_steps && rc == FMX_OK; ++g) {
       const int n = group_size(g, first_step);
       const int next_first = first_step + n;
-      if (sd) {
-        if (next_first < n_steps) {  // sort the next group while this one runs
-          if (g >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[(g + 1) & 1], 0);  // group g-1 is done with that half
-          rc = sort_group(g + 1, next_first, group_size(g + 1, next_first), sd->stream);
-          (void)hipEventRecord(sd->sorted[(g + 1) & 1], sd->stream);
-        }
-      } else {
-        rc = sort_group(g, first_step, n, st);
-      }
+      if (!sd) rc = sort_group(g, first_step, n, st);
       for (int i = 0; i < n && rc == FMX_OK; ++i) {
         const int s = first_step + i, j = s % n_pool;
         const int32_t *idx = idx_pool + (size_t)j * B * F;
@@ -2568,6 +2268,13 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
         if (rc == FMX_OK)
           rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b,
                            loss_out ? loss_out + s : nullptr, st, nullptr, fwd->sample_ld, fwd->error);
+        // the next group is sorted while this one runs; its launch is issued BEHIND the group's first step, so that at the start
+        // of a call -- the device idle, every launch waiting for the host -- the first forward and update are not held up by it
+        if (sd && i == 0 && next_first < n_steps && rc == FMX_OK) {
+          if (g >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[(g + 1) & 1], 0);  // group g-1 is done with that half
+          rc = sort_group(g + 1, next_first, group_size(g + 1, next_first), sd->stream);
+          (void)hipEventRecord(sd->sorted[(g + 1) & 1], sd->stream);
+        }
       }
       if (sd) (void)hipEventRecord(sd->consumed[g & 1], st);
       first_step = next_first;

@@ -190,6 +190,31 @@ class FMEngine:
                                           self.workspace.data_ptr(), C.byref(out), _ptr(loss_out), ms, self._stream()))
         return None if ms is None else [float(v) for v in ms]
 
+    def prepare_stream(self, hyper, rule, loss, idx_pool, y_pool, loss_out=None, stream=None):
+        """-> run(n_steps): the online loop of stream() with every argument but the step count bound once (the structs, the
+        device pointers and the HIP stream handle: `stream`, a torch stream or an int handle, else the stream current NOW).
+        A call is then one foreign call -- what stream() spends in Python before it (building the output struct, looking up
+        the current stream: tens of microseconds) is as long as two steps of the loop.  The caller keeps idx_pool, y_pool and
+        loss_out alive and does not grow the engine between prepare and run."""
+        n_pool, B, F = idx_pool.shape
+        assert F == self.table.n_fields and y_pool.shape == (n_pool, B)
+        assert loss_out is None or loss_out.is_contiguous()
+        self._ensure(B)
+        out = self._fwd_out(want_first=False, want_bi=False)
+        fn, check = self.lib.fmx_fm_stream, _lib.check
+        fixed = (self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss], idx_pool.data_ptr(), y_pool.data_ptr(),
+                 n_pool, B, 1.0 / B)
+        tail = (self.workspace.data_ptr(), C.byref(out), _ptr(loss_out), None, self._stream(stream))
+        cap = None if loss_out is None else loss_out.numel()
+        keep = (out, hyper, idx_pool, y_pool, loss_out, self.workspace)   # referenced by the closure: stay alive with it
+
+        def run(n_steps):
+            if cap is not None and n_steps > cap:
+                raise ValueError(f"loss_out holds {cap} steps, {n_steps} asked for")
+            check(fn(*fixed, n_steps, *tail))
+        run.keep = keep
+        return run
+
     # ---- the small fused MLP (online steps of DeepFM / NFM / ONN); shapes beyond its limits raise FmxError(UNSUPPORTED) ----
     MLP_MAX_B, MLP_MAX_W, MLP_MAX_L = 16, 64, 8
 
