@@ -84,6 +84,9 @@ struct FwdArgs {
   int32_t B, F, kp, stride, zoff, loss_kind;
   int32_t ldS, ld1;  // floats between consecutive samples in out.S and in out.dz / out.loss (kp and 1 when dense)
   float inv_b;
+  // fields as pieces of index columns (fmx_table_t.field_cols / field_base; both null on ordinary tables): Fc = columns of idx
+  const int32_t *fcols, *fbase;
+  int32_t Fc;
 };
 
 // The part of the forward pass behind the row gather: field sums (butterfly over the lane groups), bi-interaction, logit,
@@ -142,7 +145,9 @@ __device__ __forceinline__ void forward_finish(const FwdArgs &a, const int b, co
 
 // NPASS > 0: the field loop is fully unrolled (F <= NPASS * SLOTS) and every index, value, offset and row load of the
 // sample is issued before the first use, so one wave keeps up to 3 * NPASS row requests in flight.  NPASS == 0: generic.
-template <int LPR, int LAYOUT, int NPASS>
+// MAPPED (tables whose fields are pieces of index columns; the generic field loop only): field f reads column fcols[f], holds
+// the indices [fbase[f], fbase[f] + rows) of it, and an index outside belongs to another piece: no contribution, no error.
+template <int LPR, int LAYOUT, int NPASS, bool MAPPED = false>
 __device__ __forceinline__ void forward_sample(const FwdArgs &a, const int b, const int lane) {
   constexpr int SLOTS = WAVE / LPR;
   constexpr int NP = NPASS > 0 ? NPASS : 1;
@@ -188,8 +193,13 @@ __device__ __forceinline__ void forward_sample(const FwdArgs &a, const int b, co
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const size_t o = (size_t)b * a.F + fc[p];
-      li[p] = (uint32_t)a.idx[o];
+      size_t o = (size_t)b * a.F + fc[p];
+      uint32_t fb = 0u;
+      if (MAPPED) {
+        o = (size_t)b * a.Fc + (a.fcols ? a.fcols[fc[p]] : fc[p]);
+        fb = a.fbase ? (uint32_t)a.fbase[fc[p]] : 0u;
+      }
+      li[p] = (uint32_t)a.idx[o] - fb;  // (wraps to a huge value below the piece)
       xl[p] = xsrc[o];
     }
 #pragma unroll
@@ -218,40 +228,43 @@ __device__ __forceinline__ void forward_sample(const FwdArgs &a, const int b, co
         ss = ss + e * e;
         fo += f1;
       }
-      bad = bad || (live[p] && !ok[p]);
+      bad = bad || (!MAPPED && live[p] && !ok[p]);
       if (live[p] && a.out.first && q == 0) a.out.first[(size_t)b * a.F + (it * NP + p) * SLOTS + slot] = f1;
     }
   }
   forward_finish<LPR, LAYOUT>(a, b, lane, s, ss, fo, bad, y_early, bias0_early, bias1_early);
 }
 
-template <int LPR, int LAYOUT, int NPASS>
+template <int LPR, int LAYOUT, int NPASS, bool MAPPED = false>
 __global__ __launch_bounds__(256) void k_fm_forward(FwdArgs a) {
   __builtin_amdgcn_s_setprio(3);  // ahead of the side-stream sort's waves at the CU's instruction arbiter
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= a.B) return;  // wave-uniform
-  forward_sample<LPR, LAYOUT, NPASS>(a, b, threadIdx.x & 63);
+  forward_sample<LPR, LAYOUT, NPASS, MAPPED>(a, b, threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // k_fm_forward_part / k_fm_forward_finish: the forward pass split over FIELD OWNERS (model-parallel multi-GPU mode)
 // ------------------------------------------------------------------------------------------------------------
 // k_fm_forward sums a sample's rows in a fixed tree: lane group `slot` (of SLOTS = 64 / LPR) adds the fields
-// slot, SLOTS + slot, 2 SLOTS + slot, ... in order, then a butterfly over the lane groups (slot ^ 1, ^ 2, ^ 4, ...).  With G
-// ranks (G a power of two dividing SLOTS) rank g owns the fields of the lane groups [g SL, (g + 1) SL), SL = SLOTS / G, holds
-// only those fields' rows, and k_fm_forward_part evaluates exactly that sub-tree for EVERY sample of the global batch:
-// G samples per wave, SL lane groups each, the butterfly levels below SL -- one record (S_part[kp], ss_part[kp], fo_part)
-// per sample.  The records of a sample meet on the rank that holds its label (an all-to-all), where k_fm_forward_finish adds
-// them in the order of the remaining butterfly levels, ((r0 + r1) + (r2 + r3)) + ..., and runs k_fm_forward's epilogue.
-// The result is bit-identical to k_fm_forward on one GPU holding every field: same additions, same order.
+// slot, SLOTS + slot, 2 SLOTS + slot, ... in order, then a butterfly over the lane groups (slot ^ 1, ^ 2, ^ 4, ...).  The tree is
+// cut into NB BLOCKS of SL = SLOTS / NB consecutive lane groups (NB a power of two); an owner holds one or more blocks -- the
+// fields at their positions, as a table of its own: local field (lb NP + p) SL + s is position p SLOTS + (first block + lb) SL + s
+// of the whole tree -- and k_fm_forward_part evaluates exactly those sub-trees for EVERY sample of the global batch: NB samples
+// per wave, SL lane groups each, the butterfly levels below SL -- one record (S_part[kp], ss_part[kp], fo_part) per sample
+// and block.  The records of a sample meet on the rank that holds its label (an all-to-all), where k_fm_forward_finish adds
+// them in the order of the remaining butterfly levels, ((b0 + b1) + (b2 + b3)) + ..., and runs k_fm_forward's epilogue.
+// The result is bit-identical to k_fm_forward on one GPU whose table has the same fields at the same positions.
 struct PartArgs {
   const float *rows;
-  const int64_t *foff;   // the owner's LOCAL table: field l of it is global field (l / SL) * SLOTS + g * SL + l % SL
-  const int32_t *idx;    // [B, F] over the owner's fields, B = global batch
-  const float *xv;       // [B, F] or null
-  float *rec;            // [B, 2 kp + 4]: S | ss | fo, 0, 0, 0
+  const int64_t *foff;   // the owner's LOCAL table (blockIdx.y = local block lb): fields [lb NP SL, (lb + 1) NP SL) are the block's
+  const int32_t *fcols, *fbase;  // fmx_table_t.field_cols / field_base, or null
+  const int32_t *idx;    // [B, Fc], B = global batch
+  const float *xv;       // [B, Fc] or null
+  float *rec;            // [B / group][n_blocks][group, 2 kp + 4]: S | ss | fo, 0, 0, 0 -- the records of the `group` samples one rank
+                         // holds the labels of lie together, block after block: one contiguous message per destination
   int32_t *error;
-  int32_t B, F, stride, sl_log2;
+  int32_t B, F, Fc, stride, sl_log2, group;  // F: fields of the table (all blocks)
 };
 
 template <int LPR, int NPASS>
@@ -265,6 +278,8 @@ __global__ __launch_bounds__(256) void k_fm_forward_part(PartArgs a) {
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int b = wave * (SLOTS >> a.sl_log2) + (slot >> a.sl_log2);
   const bool valid = b < a.B;
+  const int f0 = (int)blockIdx.y * NPASS * SL;  // first field of this block
+  const bool pieces = a.fcols || a.fbase;
   // branch-free gather, as in forward_sample: every offset and index load, then every row load, then the sums by selects
   uint32_t li[NPASS], vocab[NPASS];
   float x[NPASS], xl[NPASS];
@@ -276,19 +291,23 @@ __global__ __launch_bounds__(256) void k_fm_forward_part(PartArgs a) {
   const int bc = valid ? b : 0;
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
-    const int f = p * SL + slot_l;
+    const int f = f0 + p * SL + slot_l;
     live[p] = valid && f < a.F;
     fc[p] = f < a.F ? f : a.F - 1;
   }
+  int colp[NPASS];
+  uint32_t fb[NPASS];
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
     lo[p] = a.foff[fc[p]];
     hi[p] = a.foff[fc[p] + 1];
+    colp[p] = a.fcols ? a.fcols[fc[p]] : fc[p];
+    fb[p] = a.fbase ? (uint32_t)a.fbase[fc[p]] : 0u;
   }
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
-    const size_t o = (size_t)bc * a.F + fc[p];
-    li[p] = (uint32_t)a.idx[o];
+    const size_t o = (size_t)bc * a.Fc + colp[p];
+    li[p] = (uint32_t)a.idx[o] - fb[p];  // (wraps to a huge value below the piece)
     xl[p] = xsrc[o];
   }
 #pragma unroll
@@ -317,10 +336,10 @@ __global__ __launch_bounds__(256) void k_fm_forward_part(PartArgs a) {
       ss = ss + e * e;
       fo += rw[p] * x[p];
     }
-    bad = bad || (live[p] && !ok[p]);
+    bad = bad || (!pieces && live[p] && !ok[p]);
   }
   if (bad && a.error) *a.error = 1;
-  // the butterfly levels inside the owner's lane groups (wave-uniform conditions)
+  // the butterfly levels inside the block's lane groups (wave-uniform conditions)
 #define FMX_BFLY_L(M)                              \
   if (LPR <= M && (M / LPR) < SL) {                \
     s = s + xor_lane_f4<M>(s, lane);               \
@@ -330,7 +349,8 @@ __global__ __launch_bounds__(256) void k_fm_forward_part(PartArgs a) {
   FMX_BFLY_L(1) FMX_BFLY_L(2) FMX_BFLY_L(4) FMX_BFLY_L(8) FMX_BFLY_L(16) FMX_BFLY_L(32)
 #undef FMX_BFLY_L
   if (valid && slot_l == 0) {
-    float *r = a.rec + (size_t)b * REC;
+    const int dst = b / a.group;
+    float *r = a.rec + (((size_t)dst * gridDim.y + blockIdx.y) * a.group + (b - dst * a.group)) * REC;
     *reinterpret_cast<float4 *>(r + 4 * q) = s;
     *reinterpret_cast<float4 *>(r + kp + 4 * q) = ss;
     if (q == 0) *reinterpret_cast<float4 *>(r + 2 * kp) = float4{fo, 0.f, 0.f, 0.f};
@@ -435,7 +455,8 @@ struct UpdArgs {
   fmx_hyper_t h;
   int32_t B, F, Bp, bbits, kp, stride, zoff;
   int32_t ldS, ld1;  // floats between consecutive samples in S and in dz_first / dz_bi / loss_b (kp and 1 when dense)
-  const int32_t *cols;  // sort field -> field (column of xv), or null; Fx: columns of xv
+  const int32_t *cols;  // sort field -> field, or null; fcols: field -> column of xv, or null; Fx: columns of xv
+  const int32_t *fcols;
   int32_t Fx;
   uint32_t seq;      // INL: launch sequence number tagging the tile meta words of this launch
   int32_t *error;    // INL: set to 2 if a hand-off wait ran into its bound
@@ -649,7 +670,8 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   {
     const bool has_x = a.xv != nullptr;
     const float *xsrc = has_x ? a.xv : a.dz_first;  // something loadable
-    const int col = (has_x && a.cols) ? a.cols[f] : f;
+    const int fld = (has_x && a.cols) ? a.cols[f] : f;
+    const int col = (has_x && a.fcols) ? a.fcols[fld] : fld;
     const float *bisrc = a.dz_bi ? a.dz_bi : a.dz_first;
     float4 S4[EPG], G4[EPG];
     float xl[EPG], dzf[EPG], dzbl[EPG];
@@ -1529,6 +1551,7 @@ int check_table(const fmx_table_t *t) {
   if (t->n_sort_fields < 0 || (t->n_sort_fields > 0 && (t->n_sort_fields < t->n_fields || !t->sort_offsets || !t->sort_cols ||
                                                         t->max_sort_field_rows < 1 || t->max_sort_field_rows > t->max_field_rows)))
     return fail(FMX_ERR_SHAPE, "sort fields: n_sort_fields >= n_fields with sort_offsets, sort_cols and max_sort_field_rows, or 0");
+  if (t->n_cols < 0 || (t->field_cols && t->n_cols < 1)) return fail(FMX_ERR_SHAPE, "field_cols needs n_cols >= 1");
   return FMX_OK;
 }
 
@@ -1544,6 +1567,8 @@ int check_rule(const fmx_table_t *t, int rule) {
 }
 
 // the SORT fields of a table: its fields, or the finer partition fmx_table_t.sort_offsets describes
+inline bool mapped(const fmx_table_t *t) { return t->field_cols || t->field_base; }  // fields are pieces of index columns
+inline int n_cols(const fmx_table_t *t) { return t->n_cols > 0 ? t->n_cols : t->n_fields; }
 inline int n_sort_fields(const fmx_table_t *t) { return t->n_sort_fields > 0 ? t->n_sort_fields : t->n_fields; }
 inline const int64_t *sort_offsets(const fmx_table_t *t) { return t->n_sort_fields > 0 ? t->sort_offsets : t->field_offsets; }
 inline const int32_t *sort_cols(const fmx_table_t *t) { return t->n_sort_fields > 0 ? t->sort_cols : nullptr; }
@@ -1620,6 +1645,18 @@ Workspace carve(const fmx_table_t *t, int B, void *base) {
   return w;
 }
 
+// the caller's workspace against what a step of B samples on this table needs NOW (the table's sort fields may have been
+// split since the buffer was sized: fmx_workspace_bytes grows with them)
+int check_workspace(const fmx_table_t *t, int B, const void *workspace, int64_t workspace_bytes, const char *who) {
+  if (!workspace) return fail(FMX_ERR_ARG, "%s: null workspace", who);
+  if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "%s: workspace must be 16-byte aligned", who);
+  const int64_t need = (int64_t)carve(t, B, nullptr).bytes;
+  if (workspace_bytes < need)
+    return fail(FMX_ERR_SHAPE, "%s: workspace of %lld bytes, %lld needed for B = %d and %d sort fields (fmx_workspace_bytes)", who,
+                (long long)workspace_bytes, (long long)need, B, n_sort_fields(t));
+  return FMX_OK;
+}
+
 // ---- a library-owned side stream per device: the occurrence sort does not depend on the weights, so it runs beside
 //      the forward pass (fmx_fm_step) or one batch ahead (fmx_fm_stream).  Created on first use, never destroyed. ----
 struct Side {
@@ -1669,6 +1706,13 @@ template <int LPR>
 void launch_forward(const FwdArgs &a, int layout, hipStream_t st) {
   const int slots = WAVE / LPR;
   const int np = (a.F + slots - 1) / slots;
+  if (a.fcols || a.fbase) {  // fields are pieces of index columns: the generic field loop (the additions and their order are the same)
+    const int wpb = tune().wpb_fwd;
+    const dim3 grid((a.B + wpb - 1) / wpb), block(64 * wpb);
+    if (layout == FMX_LAYOUT_WEIGHTS) hipLaunchKernelGGL((k_fm_forward<LPR, FMX_LAYOUT_WEIGHTS, 0, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_fm_forward<LPR, FMX_LAYOUT_FTRL, 0, true>), grid, block, 0, st, a);
+    return;
+  }
   switch (np) {
     case 1: launch_forward_np<LPR, 1>(a, layout, st); break;
     case 2: launch_forward_np<LPR, 2>(a, layout, st); break;
@@ -1789,7 +1833,9 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
   a.error = error;
   a.B = B;
   a.F = n_sort_fields(table);
-  a.Fi = table->n_fields;
+  a.Fi = n_cols(table);
+  a.fcols = table->field_cols;
+  a.fbase = table->field_base;
   a.Bp = fmx_sorted_width(B);
   a.bbits = fmx_sorted_bbits(B);
   // the chunked form wins on LATENCY (one or two batches per launch: the prefetched global sorts of the multi-GPU modes, a
@@ -1841,6 +1887,9 @@ FwdArgs fill_fwd(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32
   a.h = *hyper;
   a.B = B;
   a.F = table->n_fields;
+  a.Fc = n_cols(table);
+  a.fcols = table->field_cols;
+  a.fbase = table->field_base;
   a.kp = table->kp;
   a.stride = table->row_stride;
   a.zoff = table->z_offset;
@@ -1877,7 +1926,8 @@ UpdArgs fill_upd(const fmx_table_t *table, const fmx_hyper_t *hyper, const Works
   a.rows = table->rows;
   a.foff = sort_offsets(table);  // the update walks the SORT fields' lists; a sort field's rows start at its own offset
   a.cols = sort_cols(table);
-  a.Fx = table->n_fields;
+  a.Fx = n_cols(table);
+  a.fcols = table->field_cols;
   a.bias = table->bias;
   a.sorted = sorted;
   a.parts = w.parts;
@@ -1961,9 +2011,9 @@ void launch_online_mlp(const OnlineMlpArgs &a, int layout, int rule, hipStream_t
 }
 
 template <int LPR>
-int launch_forward_part(const PartArgs &a, int np, hipStream_t st) {
+int launch_forward_part(const PartArgs &a, int np, int n_local_blocks, hipStream_t st) {
   const int per_wave = (WAVE / LPR) >> a.sl_log2, waves = (a.B + per_wave - 1) / per_wave;
-  const dim3 grid((waves + 3) / 4), block(256);
+  const dim3 grid((waves + 3) / 4, n_local_blocks), block(256);
   switch (np) {
     case 1: hipLaunchKernelGGL((k_fm_forward_part<LPR, 1>), grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL((k_fm_forward_part<LPR, 2>), grid, block, 0, st, a); break;
@@ -1994,6 +2044,45 @@ int launch_forward_finish(const FinishArgs &a, int layout, int G, hipStream_t st
   if (G > WAVE / LPR) return fail(FMX_ERR_ARG, "fmx_fm_forward_finish: more owners than lane groups");
   return layout == FMX_LAYOUT_WEIGHTS ? launch_forward_finish_g<LPR, FMX_LAYOUT_WEIGHTS>(a, G, st)
                                       : launch_forward_finish_g<LPR, FMX_LAYOUT_FTRL>(a, G, st);
+}
+
+// the tree cut into n_blocks blocks, the table holding n_local_blocks of them: fields [lb NP SL, (lb + 1) NP SL) are block lb's
+int part_impl(const fmx_table_t *table, const int32_t *idx, const float *xv, int32_t B, int32_t n_blocks, int32_t n_local_blocks,
+              int32_t group, float *parts_out, int32_t *error, hipStream_t st) {
+  if (group <= 0) group = B;
+  if (B % group) return fail(FMX_ERR_SHAPE, "fmx_fm_forward_partial: B = %d is not a multiple of group = %d", B, group);
+  const int lpr = lpr_of(table->kp), slots = WAVE / lpr;
+  if (n_blocks < 1 || n_blocks > slots || (n_blocks & (n_blocks - 1))) return fail(FMX_ERR_ARG, "n_blocks must be a power of two <= %d", slots);
+  if (n_local_blocks < 1 || n_local_blocks > n_blocks) return fail(FMX_ERR_ARG, "n_local_blocks must be in [1, n_blocks]");
+  const int sl = slots / n_blocks;
+  if (n_local_blocks > 1 && table->n_fields % (n_local_blocks * sl))  // (one block: a ragged last pass is fine)
+    return fail(FMX_ERR_SHAPE, "a table of %d blocks of %d lane groups holds a multiple of %d fields (empty fields fill the holes), not %d",
+                n_local_blocks, sl, n_local_blocks * sl, table->n_fields);
+  int sl_log2 = 0;
+  while ((1 << sl_log2) < sl) ++sl_log2;
+  PartArgs a;
+  a.rows = table->rows;
+  a.foff = table->field_offsets;
+  a.fcols = table->field_cols;
+  a.fbase = table->field_base;
+  a.idx = idx;
+  a.xv = xv;
+  a.rec = parts_out;
+  a.error = error;
+  a.B = B;
+  a.F = table->n_fields;
+  a.Fc = n_cols(table);
+  a.stride = table->row_stride;
+  a.sl_log2 = sl_log2;
+  a.group = group;
+  const int np = (table->n_fields + n_local_blocks * sl - 1) / (n_local_blocks * sl);
+  switch (lpr) {
+    case 1: return launch_forward_part<1>(a, np, n_local_blocks, st);
+    case 2: return launch_forward_part<2>(a, np, n_local_blocks, st);
+    case 4: return launch_forward_part<4>(a, np, n_local_blocks, st);
+    case 8: return launch_forward_part<8>(a, np, n_local_blocks, st);
+    default: return launch_forward_part<16>(a, np, n_local_blocks, st);
+  }
 }
 
 int check_forward_args(const fmx_table_t *table, const fmx_hyper_t *hyper, const int32_t *idx, const float *y, int32_t B,
@@ -2075,37 +2164,13 @@ int fmx_fm_forward(const fmx_table_t *table, const fmx_hyper_t *hyper, const int
   return forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, out, static_cast<hipStream_t>(stream));
 }
 
-int fmx_fm_forward_partial(const fmx_table_t *table, const int32_t *idx, const float *xv, int32_t B, int32_t n_owners,
-                           float *parts_out, int32_t *error, fmx_stream_t stream) {
+int fmx_fm_forward_partial(const fmx_table_t *table, const int32_t *idx, const float *xv, int32_t B, int32_t n_blocks,
+                           int32_t n_local_blocks, int32_t group, float *parts_out, int32_t *error, fmx_stream_t stream) {
   if (int rc = check_table(table)) return rc;
   if (!idx || !parts_out) return fail(FMX_ERR_ARG, "fmx_fm_forward_partial: null argument");
   if (B < 1) return fail(FMX_ERR_ARG, "B must be >= 1");
   if (!aligned16(parts_out)) return fail(FMX_ERR_ALIGN, "parts_out must be 16-byte aligned");
-  const int lpr = lpr_of(table->kp), slots = WAVE / lpr;
-  if (n_owners < 1 || n_owners > slots || (n_owners & (n_owners - 1))) return fail(FMX_ERR_ARG, "n_owners must be a power of two <= %d", slots);
-  const int sl = slots / n_owners;
-  int sl_log2 = 0;
-  while ((1 << sl_log2) < sl) ++sl_log2;
-  PartArgs a;
-  a.rows = table->rows;
-  a.foff = table->field_offsets;
-  a.idx = idx;
-  a.xv = xv;
-  a.rec = parts_out;
-  a.error = error;
-  a.B = B;
-  a.F = table->n_fields;
-  a.stride = table->row_stride;
-  a.sl_log2 = sl_log2;
-  const int np = (table->n_fields + sl - 1) / sl;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (lpr) {
-    case 1: return launch_forward_part<1>(a, np, st);
-    case 2: return launch_forward_part<2>(a, np, st);
-    case 4: return launch_forward_part<4>(a, np, st);
-    case 8: return launch_forward_part<8>(a, np, st);
-    default: return launch_forward_part<16>(a, np, st);
-  }
+  return part_impl(table, idx, xv, B, n_blocks, n_local_blocks, group, parts_out, error, static_cast<hipStream_t>(stream));
 }
 
 int fmx_fm_forward_finish(const fmx_hyper_t *hyper, const float *bias, int32_t layout, int32_t kp, const float *parts,
@@ -2144,17 +2209,18 @@ int fmx_fm_forward_finish(const fmx_hyper_t *hyper, const float *bias, int32_t l
   }
 }
 
-int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, void *workspace, int32_t *error,
+int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, void *workspace, int64_t workspace_bytes, int32_t *error,
                          fmx_stream_t stream) {
   if (int rc = check_table(table)) return rc;
   if (!idx || !workspace) return fail(FMX_ERR_ARG, "fmx_sort_occurrences: null argument");
   if (!aligned16(workspace)) return fail(FMX_ERR_ALIGN, "workspace must be 16-byte aligned");
   if (int rc = check_sort_geometry(table, B)) return rc;
+  if (int rc = check_workspace(table, B, workspace, workspace_bytes, "fmx_sort_occurrences")) return rc;
   const Workspace w = carve(table, B, workspace);
   return sort_impl(table, idx, B, w.sorted, w.runs, error, static_cast<hipStream_t>(stream));
 }
 
-int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, void *workspace, const float *xv,
+int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, void *workspace, int64_t workspace_bytes, const float *xv,
                   const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
                   int32_t sample_ld, const float *loss_b, float inv_b, float *loss_out, fmx_stream_t stream) {
   if (int rc = check_table(table)) return rc;
@@ -2167,17 +2233,19 @@ int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
   if (!aligned16(workspace) || !aligned16(S) || (gbi && !aligned16(gbi)) ||
       (sample_ld == 0 && (!aligned16(dz_first) || (loss_b && !aligned16(loss_b)))))
     return fail(FMX_ERR_ALIGN, "workspace, S, gbi (and dense dz_first / loss_b) must be 16-byte aligned");
+  if (int rc = check_workspace(table, B, workspace, workspace_bytes, "fmx_fm_update")) return rc;
   const Workspace w = carve(table, B, workspace);
   return update_impl(table, hyper, rule, w, w.sorted, xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out,
                      static_cast<hipStream_t>(stream), nullptr, sample_ld);
 }
 
 int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
-                const int32_t *idx, const float *xv, const float *y, int32_t B, float inv_b, void *workspace,
+                const int32_t *idx, const float *xv, const float *y, int32_t B, float inv_b, void *workspace, int64_t workspace_bytes,
                 const fmx_fwd_out_t *fwd, float *loss_out, fmx_stream_t stream) {
   if (int rc = check_step_args(table, hyper, rule, loss_kind, B, workspace, fwd)) return rc;
   if (!idx || !y) return fail(FMX_ERR_ARG, "fmx_fm_step: idx and y are required");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = check_workspace(table, B, workspace, workspace_bytes, "fmx_fm_step")) return rc;
   const Workspace w = carve(table, B, workspace);
   Side *sd = B >= OVERLAP_MIN_BATCH ? side_for_current_device() : nullptr;
   if (sd) {  // sort beside the forward pass: fork -> {side: sort} || {main: forward} -> join -> update
@@ -2197,13 +2265,14 @@ int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
 
 int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
                   const int32_t *idx_pool, const float *y_pool, int32_t n_pool, int32_t B, float inv_b,
-                  int32_t n_steps, void *workspace, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
+                  int32_t n_steps, void *workspace, int64_t workspace_bytes, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
                   fmx_stream_t stream) {
   if (int rc = check_step_args(table, hyper, rule, loss_kind, B, workspace, fwd)) return rc;
   if (!idx_pool || !y_pool || n_pool < 1 || n_steps < 0) return fail(FMX_ERR_ARG, "fmx_fm_stream: bad pool / step count");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = check_workspace(table, B, workspace, workspace_bytes, "fmx_fm_stream")) return rc;
   const Workspace w = carve(table, B, workspace);
-  const size_t F = (size_t)table->n_fields;
+  const size_t F = (size_t)n_cols(table);
   int rc = FMX_OK;
 
   if (!kernel_ms) {
@@ -2370,6 +2439,7 @@ int fmx_fm_online_run(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_
                       int32_t *error, fmx_stream_t stream) {
   if (int rc = check_table(table)) return rc;
   if (int rc = check_rule(table, rule)) return rc;
+  if (mapped(table)) return fail(FMX_ERR_UNSUPPORTED, "fmx_fm_online_run: tables whose fields are pieces of index columns are not taken");
   if (N < 0) return fail(FMX_ERR_ARG, "fmx_fm_online_run: N must be >= 0");
   if (N == 0) return FMX_OK;  // an empty stream (its buffers may be null)
   if (!hyper || !idx || !y || !pred_out) return fail(FMX_ERR_ARG, "fmx_fm_online_run: null argument");
@@ -2425,11 +2495,12 @@ static int mlp_launch(const fmx_mlp_t *mlp, MlpArgs &a, int32_t B, int32_t kp, f
 
 int fmx_online_run_mlp(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
                        const fmx_mlp_t *mlp, int32_t hedge, int32_t fm_term, float hedge_b, float hedge_s, float *alpha,
-                       const int32_t *idx, const float *xv, const float *y, int32_t N, void *workspace,
+                       const int32_t *idx, const float *xv, const float *y, int32_t N, void *workspace, int64_t workspace_bytes,
                        const fmx_fwd_out_t *fwd, float *scratch, float *pred_out, fmx_stream_t stream) {
   if (int rc = check_table(table)) return rc;
   if (!hyper || !mlp || !idx || !y || !workspace || !fwd || !scratch || !pred_out)
     return fail(FMX_ERR_ARG, "fmx_online_run_mlp: null argument");
+  if (mapped(table)) return fail(FMX_ERR_UNSUPPORTED, "fmx_online_run_mlp: tables whose fields are pieces of index columns are not taken");
   if (!fwd->S || !fwd->bi || !fwd->sfirst || !fwd->logit) return fail(FMX_ERR_ARG, "fmx_online_run_mlp: fwd needs S, bi, sfirst, logit");
   if (!aligned16(workspace) || !aligned16(scratch)) return fail(FMX_ERR_ALIGN, "workspace and scratch must be 16-byte aligned");
   if (hedge && !alpha) return fail(FMX_ERR_ARG, "fmx_online_run_mlp: Hedge needs alpha");
@@ -2488,6 +2559,7 @@ int fmx_online_run_mlp(const fmx_table_t *table, const fmx_hyper_t *hyper, int32
       return check_launch("k_online_mlp");
     }
   }
+  if (int rc = check_workspace(table, 1, workspace, workspace_bytes, "fmx_online_run_mlp")) return rc;
   const Workspace w = carve(table, 1, workspace);
   const size_t F = (size_t)table->n_fields;
   fmx_fwd_out_t f1 = *fwd;  // one sample: dense outputs

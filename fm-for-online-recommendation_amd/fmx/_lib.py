@@ -35,7 +35,8 @@ class Table(C.Structure):
                 ("n_fields", C.c_int32), ("k", C.c_int32), ("kp", C.c_int32), ("row_stride", C.c_int32),
                 ("layout", C.c_int32), ("z_offset", C.c_int32), ("max_field_rows", C.c_int64),
                 ("sort_offsets", C.c_void_p), ("sort_cols", C.c_void_p), ("n_sort_fields", C.c_int32), ("reserved", C.c_int32),
-                ("max_sort_field_rows", C.c_int64)]
+                ("max_sort_field_rows", C.c_int64), ("field_cols", C.c_void_p), ("field_base", C.c_void_p),
+                ("n_cols", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class Hyper(C.Structure):
@@ -74,18 +75,18 @@ def load():
     lib.fmx_sorted_bbits.argtypes = [C.c_int]
     lib.fmx_workspace_bytes.argtypes = [TP, i32]
     lib.fmx_fm_forward.argtypes = [TP, HP, p, p, p, i32, i32, f32, FP, p]
-    lib.fmx_sort_occurrences.argtypes = [TP, p, i32, p, p, p]
+    lib.fmx_sort_occurrences.argtypes = [TP, p, i32, p, i64, p, p]
     lib.fmx_sftrl_run.argtypes = [p, p, i32, i32, i32, i32, C.c_double, C.c_double, i32, p, p, p, p, p, p, p, p]
     lib.fmx_sftrl_grid.argtypes = [p, p, i32, i32, i32, i32, p, p, i32, C.c_double, i32, p, p, p, p, p, p, p, p]
-    lib.fmx_fm_forward_partial.argtypes = [TP, p, p, i32, i32, p, p, p]
+    lib.fmx_fm_forward_partial.argtypes = [TP, p, p, i32, i32, i32, i32, p, p, p]
     lib.fmx_fm_forward_finish.argtypes = [HP, p, i32, i32, p, i64, i32, p, i32, i32, f32, FP, p]
-    lib.fmx_fm_update.argtypes = [TP, HP, i32, p, p, p, p, p, p, i32, i32, p, f32, p, p]
-    lib.fmx_fm_step.argtypes = [TP, HP, i32, i32, p, p, p, i32, f32, p, FP, p, p]
-    lib.fmx_fm_stream.argtypes = [TP, HP, i32, i32, p, p, i32, i32, f32, i32, p, FP, p, C.POINTER(C.c_float), p]
+    lib.fmx_fm_update.argtypes = [TP, HP, i32, p, i64, p, p, p, p, p, i32, i32, p, f32, p, p]
+    lib.fmx_fm_step.argtypes = [TP, HP, i32, i32, p, p, p, i32, f32, p, i64, FP, p, p]
+    lib.fmx_fm_stream.argtypes = [TP, HP, i32, i32, p, p, i32, i32, f32, i32, p, i64, FP, p, C.POINTER(C.c_float), p]
     lib.fmx_stream_read.argtypes = [p, i64, p, p]
     lib.fmx_fm_online_run.argtypes = [TP, HP, i32, i32, p, p, p, i32, p, p, p, p]
     MP = C.POINTER(Mlp)
-    lib.fmx_online_run_mlp.argtypes = [TP, HP, i32, i32, MP, i32, i32, f32, f32, p, p, p, p, i32, p, FP, p, p, p]
+    lib.fmx_online_run_mlp.argtypes = [TP, HP, i32, i32, MP, i32, i32, f32, f32, p, p, p, p, i32, p, i64, FP, p, p, p]
     lib.fmx_mlp_forward.argtypes = [MP, p, i32, p, i32, p, p, p]
     lib.fmx_mlp_fit.argtypes = [MP, HP, i32, i32, p, i32, p, p, i32, f32, p, p, p, p]
     lib.fmx_mlp_hedge_fit.argtypes = [MP, f32, f32, f32, p, p, i32, p, p, i32, p, p]

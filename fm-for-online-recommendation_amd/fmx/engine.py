@@ -82,6 +82,9 @@ class FMEngine:
         self.error = torch.zeros(1, dtype=torch.int32, device=dev)
         self.max_batch = B
 
+    def _ws_bytes(self):
+        return self.workspace.numel() * self.workspace.element_size()
+
     def _ensure(self, B):
         if B > self.max_batch:
             self._alloc(B)
@@ -143,7 +146,7 @@ class FMEngine:
         B = idx_d.shape[0]
         self._ensure(B)
         ws = self.workspace if workspace is None else workspace
-        _lib.check(self.lib.fmx_sort_occurrences(self.table.c_struct(), idx_d.data_ptr(), B, ws.data_ptr(),
+        _lib.check(self.lib.fmx_sort_occurrences(self.table.c_struct(), idx_d.data_ptr(), B, ws.data_ptr(), ws.numel() * ws.element_size(),
                                                  self.error.data_ptr(), self._stream(stream)))
 
     def update(self, hyper, rule, B, xv_d, dz_first, dz_bi=None, gbi=None, inv_b=None, with_loss=True, S=None, loss_b=None,
@@ -163,7 +166,7 @@ class FMEngine:
             loss_b = self.loss_b if loss_b is None else loss_b
             S_p, dzf_p, dzb_p, loss_p = S.data_ptr(), dz_first.data_ptr(), _ptr(dz_bi), loss_b.data_ptr()
         ws = self.workspace if workspace is None else workspace
-        _lib.check(self.lib.fmx_fm_update(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], ws.data_ptr(),
+        _lib.check(self.lib.fmx_fm_update(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], ws.data_ptr(), ws.numel() * ws.element_size(),
                                           _ptr(xv_d), S_p, dzf_p, dzb_p, _ptr(gbi), B, ld,
                                           loss_p if with_loss else None, inv_b,
                                           self.loss_out.data_ptr() if with_loss else None, self._stream(stream)))
@@ -175,7 +178,7 @@ class FMEngine:
         out = self._fwd_out(want_first=False, want_bi=False)
         inv_b = 1.0 / B if inv_b is None else inv_b
         _lib.check(self.lib.fmx_fm_step(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss],
-                                        idx_d.data_ptr(), _ptr(xv_d), y_d.data_ptr(), B, inv_b, self.workspace.data_ptr(),
+                                        idx_d.data_ptr(), _ptr(xv_d), y_d.data_ptr(), B, inv_b, self.workspace.data_ptr(), self._ws_bytes(),
                                         C.byref(out), self.loss_out.data_ptr(), self._stream()))
 
     def stream(self, hyper, rule, loss, idx_pool, y_pool, n_steps, loss_out=None, timed=False):
@@ -187,7 +190,7 @@ class FMEngine:
         ms = (C.c_float * 4)() if timed else None
         _lib.check(self.lib.fmx_fm_stream(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss],
                                           idx_pool.data_ptr(), y_pool.data_ptr(), n_pool, B, 1.0 / B, n_steps,
-                                          self.workspace.data_ptr(), C.byref(out), _ptr(loss_out), ms, self._stream()))
+                                          self.workspace.data_ptr(), self._ws_bytes(), C.byref(out), _ptr(loss_out), ms, self._stream()))
         return None if ms is None else [float(v) for v in ms]
 
     def prepare_stream(self, hyper, rule, loss, idx_pool, y_pool, loss_out=None, stream=None):
@@ -204,7 +207,7 @@ class FMEngine:
         fn, check = self.lib.fmx_fm_stream, _lib.check
         fixed = (self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss], idx_pool.data_ptr(), y_pool.data_ptr(),
                  n_pool, B, 1.0 / B)
-        tail = (self.workspace.data_ptr(), C.byref(out), _ptr(loss_out), None, self._stream(stream))
+        tail = (self.workspace.data_ptr(), self._ws_bytes(), C.byref(out), _ptr(loss_out), None, self._stream(stream))
         cap = None if loss_out is None else loss_out.numel()
         keep = (out, hyper, idx_pool, y_pool, loss_out, self.workspace)   # referenced by the closure: stay alive with it
 
@@ -276,7 +279,7 @@ class FMEngine:
             self._online_scratch = torch.zeros(self.table.kp + 8, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.fmx_online_run_mlp(self.table.c_struct(), hyper.ref(), _lib.RULES[rule], _lib.LOSSES[loss], C.byref(m),
                                                1 if hedge else 0, 1 if fm_term else 0, hedge_b, hedge_s, _ptr(alpha),
-                                               idx_d.data_ptr(), _ptr(xv_d), y_d.data_ptr(), N, self.workspace.data_ptr(),
+                                               idx_d.data_ptr(), _ptr(xv_d), y_d.data_ptr(), N, self.workspace.data_ptr(), self._ws_bytes(),
                                                C.byref(out), self._online_scratch.data_ptr(), pred.data_ptr(), self._stream()))
         return pred
 

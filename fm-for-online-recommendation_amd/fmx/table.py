@@ -27,9 +27,9 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def field_offsets(feature_sizes):
+def field_offsets(feature_sizes, allow_empty=False):
     sizes = [int(s) for s in feature_sizes]
-    if any(s < 1 for s in sizes):
+    if any(s < (0 if allow_empty else 1) for s in sizes) or sum(sizes) < 1:
         raise ValueError("every field needs at least one row")
     return np.concatenate([[0], np.cumsum(sizes, dtype=np.int64)]).astype(np.int64)
 
@@ -46,7 +46,11 @@ def ftrl_z_for_weight_torch(w, h):
 
 
 class FlatTable:
-    def __init__(self, feature_sizes, k, layout="weights", device=None, row_stride=None, ftrl=None):
+    def __init__(self, feature_sizes, k, layout="weights", device=None, row_stride=None, ftrl=None, field_cols=None,
+                 field_base=None, n_cols=None):
+        """field_cols / field_base / n_cols (include/fmx.h, "fields as pieces of index columns"; the multi-GPU owner mode): field f
+        holds the indices [field_base[f], field_base[f] + feature_sizes[f]) of column field_cols[f] of an idx with n_cols
+        columns; such a table may have empty fields (holes of the forward tree)."""
         if device is None:
             device = torch.device("cuda")
         self.device = torch.device(device)
@@ -73,11 +77,24 @@ class FlatTable:
         self.row_stride = default if row_stride is None else int(row_stride)
         if self.row_stride % 4 or self.row_stride < need:
             raise ValueError(f"row_stride must be a multiple of 4 and >= {need}")
-        offs = field_offsets(self.feature_sizes)
+        self.mapped = field_cols is not None
+        offs = field_offsets(self.feature_sizes, allow_empty=self.mapped)
+        if self.mapped:
+            fb = [0] * self.n_fields if field_base is None else [int(v) for v in field_base]
+            self.field_cols_host, self.field_base_host = [int(c) for c in field_cols], fb
+            assert len(self.field_cols_host) == self.n_fields == len(fb)
+            self.n_cols = int(n_cols) if n_cols is not None else max(self.field_cols_host) + 1
+            assert 0 <= min(self.field_cols_host) and max(self.field_cols_host) < self.n_cols
+        else:
+            assert field_base is None and n_cols is None
+            self.n_cols = self.n_fields
         self.offsets_host = offs
         self.n_rows = int(offs[-1])
         self.rows = torch.zeros((self.n_rows, self.row_stride), dtype=torch.float32, device=self.device)
         self.offsets = torch.from_numpy(offs).to(self.device)
+        if self.mapped:
+            self.field_cols = torch.tensor(self.field_cols_host, dtype=torch.int32, device=self.device)
+            self.field_base = torch.tensor(self.field_base_host, dtype=torch.int32, device=self.device)
         self.bias = torch.zeros(1 if layout == "weights" else 2, dtype=torch.float32, device=self.device)
         self._cstruct = None
         self._sort_split = None
@@ -99,6 +116,8 @@ class FlatTable:
             if self._sort_split is not None:
                 so, sc, mx = self._sort_split
                 t.sort_offsets, t.sort_cols, t.n_sort_fields, t.max_sort_field_rows = so.data_ptr(), sc.data_ptr(), sc.numel(), mx
+            if self.mapped:
+                t.field_cols, t.field_base, t.n_cols = self.field_cols.data_ptr(), self.field_base.data_ptr(), self.n_cols
             self._cstruct = t
         return C.byref(self._cstruct)
 
@@ -117,7 +136,7 @@ class FlatTable:
             return
         offs, cols, mx = [0], [], 0
         for f, size in enumerate(self.feature_sizes):
-            n = (size + cap - 1) // cap
+            n = max(1, (size + cap - 1) // cap)                  # (an empty field of a mapped table stays one empty sort field)
             base, lo = size // n, int(self.offsets_host[f])
             for j in range(n):
                 rows = base + (1 if j < size % n else 0)

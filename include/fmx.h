@@ -50,7 +50,8 @@
 extern "C" {
 #endif
 
-#define FMX_VERSION 100 /* 0.1.0 */
+#define FMX_VERSION 103 /* 0.1.3: fields as row-range pieces of index columns (field_cols / field_base / n_cols), workspace_bytes arguments,
+                           fmx_owner_* */
 
 typedef void *fmx_stream_t; /* hipStream_t */
 
@@ -103,6 +104,19 @@ typedef struct fmx_table {
   int32_t n_sort_fields;
   int32_t reserved;
   int64_t max_sort_field_rows;
+  /* FIELDS AS PIECES OF INDEX COLUMNS (optional; all null / 0: field f holds every index of column f).  For the multi-GPU
+   * field-owner mode a "field" of a table is a consecutive row range of one column of idx: field f reads column
+   * field_cols[f] and holds its indices [field_base[f], field_base[f] + rows_f) -- a sample whose index lies outside belongs
+   * to another piece (another field of this table, or a field of another owner's table) and contributes nothing here.  A
+   * field may be EMPTY (0 rows): a hole in the forward tree.  The forward pass adds the fields in position order (lane
+   * group f % SLOTS, pass f / SLOTS, SLOTS = 64 / (kp / 4)), so which piece sits at which field number decides the order
+   * of the floating-point additions: tables that place the same pieces at the same positions give identical bits however
+   * the positions are dealt over owners.  With pieces the kernels cannot tell a bad index from one of another piece:
+   * device-side range errors (error word 1) are reported for unmapped tables only. */
+  const int32_t *field_cols; /* [n_fields] or null */
+  const int32_t *field_base; /* [n_fields] or null */
+  int32_t n_cols;            /* columns of idx / xv; 0: n_fields */
+  int32_t reserved2;
 } fmx_table_t;
 
 typedef struct fmx_hyper {
@@ -154,6 +168,9 @@ int fmx_sorted_bbits(int B);
  *   meta    int32  [F, Bp/64, 2]     per 64-entry tile: does a run come in from / go out to the neighbouring tile; with the
  *                                    in-launch hand-off word 0 is (launch sequence << 4 | states) and is polled by later tiles
  *   parts   float  [F, Bp/64, 2, 2*kp+4]  partial sums of the runs that cross a tile boundary
+ * Every entry point that takes a workspace also takes its size in bytes and returns FMX_ERR_SHAPE when that is less than
+ * fmx_workspace_bytes(table, B) NOW: the size depends on the table's sort fields, and a table whose fields were split for a
+ * larger batch needs a larger workspace at every batch size.
  * The workspace must be ZERO-FILLED once before its first use (the hand-off's flag words are compared with a
  * non-zero launch sequence number; never-written words must not match one by accident).
  * Negative on a bad table. */
@@ -172,20 +189,23 @@ int fmx_fm_forward(const fmx_table_t *table, const fmx_hyper_t *hyper, const int
                    const float *y, int32_t B, int32_t loss_kind, float inv_b, const fmx_fwd_out_t *out,
                    fmx_stream_t stream);
 
-/* ---- the forward pass split over field owners (the model-parallel multi-GPU mode; fmx/owner.py) ----
+/* ---- the forward pass split over field owners (the model-parallel multi-GPU mode; fmx/owner.py, fmx/plan.py) ----
  * fmx_fm_forward sums a sample's rows in a fixed tree: lane group `slot` of SLOTS = 64 / (kp / 4) adds the fields slot,
- * SLOTS + slot, ... in order, then a butterfly over the lane groups.  With n_owners ranks (a power of two <= SLOTS) owner g
- * holds the fields of the lane groups [g SL, (g + 1) SL), SL = SLOTS / n_owners, as a table of its own whose field l is global
- * field (l / SL) * SLOTS + g * SL + l % SL, and fmx_fm_forward_partial evaluates that sub-tree for every sample of the GLOBAL
- * batch: parts_out [B, 2 kp + 4] = per sample (S_part[kp], sum e*e part[kp], first-order part, 0, 0, 0).  The records of a sample
- * meet on the rank that holds its label; fmx_fm_forward_finish adds them in the order of the remaining butterfly levels --
- * owner pairs, pairs of pairs, ... -- and applies fmx_fm_forward's epilogue (bias, loss, dlogit).  The outputs are
- * bit-identical to fmx_fm_forward on one device holding every field.
- *   idx [B, F_local] int32 over the owner's fields, xv likewise or null; error as in fmx_fwd_out_t
- *   parts [n_owners][B, 2 kp + 4], owner r's block owner_stride floats after owner r-1's; bias [1] or [2] as in fmx_table_t
+ * SLOTS + slot, ... in order, then a butterfly over the lane groups.  The tree is cut into n_blocks BLOCKS of SL = SLOTS /
+ * n_blocks consecutive lane groups (n_blocks a power of two <= SLOTS); an owner holds n_local_blocks of them as a table of its
+ * own: with NP = n_fields / (n_local_blocks SL) passes, local field (lb NP + p) SL + s sits at position p SLOTS + (first + lb) SL + s
+ * of the whole tree (fields are pieces of index columns: fmx_table_t.field_cols / field_base; empty fields fill the holes).
+ * fmx_fm_forward_partial evaluates those sub-trees for every sample of the GLOBAL batch: parts_out [B / group][n_local_blocks][group,
+ * 2 kp + 4] = per block and sample (S_part[kp], sum e*e part[kp], first-order part, 0, 0, 0); group (0: B) = the samples one rank
+ * holds the labels of: their records lie together, block after block -- one contiguous message per destination.  The records of a sample meet on the rank
+ * that holds its label; fmx_fm_forward_finish adds the n_blocks records in the order of the remaining butterfly levels --
+ * block pairs, pairs of pairs, ... -- and applies fmx_fm_forward's epilogue (bias, loss, dlogit).  The outputs are
+ * bit-identical to fmx_fm_forward on one device whose table has the same fields at the same positions.
+ *   idx [B, n_cols] int32 (all columns; the owner's fields pick theirs), xv likewise or null; error as in fmx_fwd_out_t
+ *   parts [n_blocks][B, 2 kp + 4], block r's records owner_stride floats after block r-1's; bias [1] or [2] as in fmx_table_t
  * Replaces: the same reference sites as fmx_fm_forward (deepfm_adam.py:46-77, fm_adam.py:35-53, :61,66 / :76,80). */
-int fmx_fm_forward_partial(const fmx_table_t *table, const int32_t *idx, const float *xv, int32_t B, int32_t n_owners,
-                           float *parts_out, int32_t *error, fmx_stream_t stream);
+int fmx_fm_forward_partial(const fmx_table_t *table, const int32_t *idx, const float *xv, int32_t B, int32_t n_blocks,
+                           int32_t n_local_blocks, int32_t group, float *parts_out, int32_t *error, fmx_stream_t stream);
 int fmx_fm_forward_finish(const fmx_hyper_t *hyper, const float *bias, int32_t layout, int32_t kp, const float *parts,
                           int64_t owner_stride, int32_t n_owners, const float *y, int32_t B, int32_t loss_kind, float inv_b,
                           const fmx_fwd_out_t *out, fmx_stream_t stream);
@@ -199,7 +219,7 @@ int fmx_fm_forward_finish(const fmx_hyper_t *hyper, const float *bias, int32_t l
  *   Bp = fmx_sorted_width(B), bbits = fmx_sorted_bbits(B); requires (largest sort field - 1) < (0xFFFFFFFF >> bbits)
  *   and Bp <= 32768 (a field's composites are merged in one workgroup's LDS).
  */
-int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, void *workspace, int32_t *error,
+int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B, void *workspace, int64_t workspace_bytes, int32_t *error,
                          fmx_stream_t stream);
 
 /* Row-reduced backward + fused per-row update.
@@ -216,7 +236,7 @@ int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B
  *   loss_b    [B] or null with loss_out [1] or null: loss_out = inv_b * sum_b loss_b (deterministic order)
  *   sample_ld 0, or the record stride of fmx_fwd_out_t.sample_ld: applies to S, dz_first, dz_bi and loss_b (gbi is dense)
  */
-int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, void *workspace,
+int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, void *workspace, int64_t workspace_bytes,
                   const float *xv, const float *S, const float *dz_first, const float *dz_bi, const float *gbi,
                   int32_t B, int32_t sample_ld, const float *loss_b, float inv_b, float *loss_out, fmx_stream_t stream);
 
@@ -225,7 +245,7 @@ int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
  * update_embedding (deepfm_adam.py:91-104 etc.), which all train on forward_fm only.
  * workspace: fmx_workspace_bytes(table, B) bytes; fwd->S, fwd->loss, fwd->dz must be non-null. */
 int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
-                const int32_t *idx, const float *xv, const float *y, int32_t B, float inv_b, void *workspace,
+                const int32_t *idx, const float *xv, const float *y, int32_t B, float inv_b, void *workspace, int64_t workspace_bytes,
                 const fmx_fwd_out_t *fwd, float *loss_out, fmx_stream_t stream);
 
 /* The online loop over a device-resident stream of mini-batches: step s uses batch (s mod n_pool).
@@ -241,7 +261,7 @@ int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
  * subtracted. */
 int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
                   const int32_t *idx_pool, const float *y_pool, int32_t n_pool, int32_t B, float inv_b,
-                  int32_t n_steps, void *workspace, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
+                  int32_t n_steps, void *workspace, int64_t workspace_bytes, const fmx_fwd_out_t *fwd, float *loss_out, float *kernel_ms,
                   fmx_stream_t stream);
 
 /* The reference's online protocol for the pure-FM class on a device-resident stream of N samples: for every sample,
@@ -295,7 +315,7 @@ int fmx_mlp_hedge_fit(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge
  * Replaces: the loop body of run_experiment (reference deepfm_adam.py:128-130, deepfm_onn.py:178-180, ...). */
 int fmx_online_run_mlp(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
                        const fmx_mlp_t *mlp, int32_t hedge, int32_t fm_term, float hedge_b, float hedge_s, float *alpha,
-                       const int32_t *idx, const float *xv, const float *y, int32_t N, void *workspace,
+                       const int32_t *idx, const float *xv, const float *y, int32_t N, void *workspace, int64_t workspace_bytes,
                        const fmx_fwd_out_t *fwd, float *scratch, float *pred_out, fmx_stream_t stream);
 
 /* The same network at mini-batch sizes (BASELINE configs[3]: 3 x 256, B = 4096), any B / hidden / k, up to 8 layers:

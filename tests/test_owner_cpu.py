@@ -29,38 +29,52 @@ def tree(parts):
 
 class OracleOwnerBackend:
     """numpy stand-in for fmx.owner.HipOwnerBackend with the same summation tree, so that G ranks and one rank add the same
-    numbers in the same order: per lane group the fields slot, 16 + slot, ... in order, then the pairwise tree."""
+    numbers in the same order: the rank's pieces (fmx.plan.OwnerPlan) sit at fixed positions; per lane group the passes in
+    order, a pairwise tree over the lane groups of a block, then over the blocks.  The state holds EVERY row (column-major,
+    plus one scratch row at the end that absent occurrences are pointed at with x = 0); a rank only touches its pieces' rows."""
 
-    def __init__(self, state, offs, rank, world):
-        from fmx.owner import owner_fields
-        self.st, self.offs, self.rank, self.world = state, offs, rank, world
-        self.fields = owner_fields(len(SIZES), K, world, rank)
-        self.sl = SLOTS // world
-        self.cols = torch.tensor(self.fields, dtype=torch.long)
+    def __init__(self, state, offs, rank, world, plan):
+        self.st, self.offs, self.rank, self.world, self.plan = state, offs, rank, world, plan
+        self.fields = plan.owner_fields(rank)                       # local fields in position order: (column, first index, rows)
+        self.nb, self.nlb, self.sl, self.np = plan.nb, plan.block_count[rank], plan.sl, plan.np
+        self.block_count = list(plan.block_count)
+        self.scratch = int(offs[-1])
 
-    def select(self, idx_all):
-        return idx_all.index_select(1, self.cols).contiguous()
+    def _occ(self, idx_all):
+        """rows [GB, n_local_fields] (the scratch row where the sample's index lies outside the piece) and the 0/1 mask."""
+        idx = idx_all.numpy().astype(np.int64)
+        rows = np.full((idx.shape[0], len(self.fields)), self.scratch, dtype=np.int64)
+        ok = np.zeros(rows.shape, dtype=bool)
+        for l, (c, b, r) in enumerate(self.fields):
+            ok[:, l] = (idx[:, c] >= b) & (idx[:, c] < b + r)
+            rows[ok[:, l], l] = self.offs[c] + idx[ok[:, l], c]
+        return rows, ok
 
-    def _rows(self, idx_own):
-        return idx_own.numpy().astype(np.int64) + self.offs[self.fields][None, :]
-
-    def partial_forward(self, idx_own):
+    def partial_forward(self, idx_all, B_local):
         st = self.st
         V = orc.ftrl_weight(st["zV"], st["nV"], **HYP)
         w = orc.ftrl_weight(st["zw"], st["nw"], **HYP)
-        rows = self._rows(idx_own)
-        GB = rows.shape[0]
-        zero = np.zeros((GB, K), f32)
-        S_slot, SS_slot, fo_slot = [zero.copy() for _ in range(self.sl)], [zero.copy() for _ in range(self.sl)], [np.zeros(GB, f32) for _ in range(self.sl)]
-        for l, f in enumerate(self.fields):           # local field l = pass * SL + lane group: passes in order per lane group
-            s = l % self.sl
-            e = V[rows[:, l]]
-            S_slot[s] = (S_slot[s] + e).astype(f32)
-            SS_slot[s] = (SS_slot[s] + e * e).astype(f32)
-            fo_slot[s] = (fo_slot[s] + w[rows[:, l]]).astype(f32)
-        rec = np.zeros((GB, 2 * K + 4), f32)
-        rec[:, :K], rec[:, K:2 * K], rec[:, 2 * K] = tree(S_slot), tree(SS_slot), tree(fo_slot)
-        return torch.from_numpy(rec)
+        rows, ok = self._occ(idx_all)
+        GB, G = rows.shape[0], rows.shape[0] // B_local
+        rec = np.zeros((G, self.nlb, B_local, 2 * K + 4), f32)
+        for lb in range(self.nlb):
+            zero = np.zeros((GB, K), f32)
+            S_slot = [zero.copy() for _ in range(self.sl)]
+            SS_slot = [zero.copy() for _ in range(self.sl)]
+            fo_slot = [np.zeros(GB, f32) for _ in range(self.sl)]
+            for p in range(self.np):                                  # passes in order per lane group; absent rows add nothing
+                for s in range(self.sl):
+                    l = (lb * self.np + p) * self.sl + s
+                    m = ok[:, l]
+                    e = V[rows[:, l]]
+                    S_slot[s] = np.where(m[:, None], (S_slot[s] + e).astype(f32), S_slot[s])
+                    SS_slot[s] = np.where(m[:, None], (SS_slot[s] + e * e).astype(f32), SS_slot[s])
+                    fo_slot[s] = np.where(m, (fo_slot[s] + w[rows[:, l]]).astype(f32), fo_slot[s])
+            S, SS, fo = tree(S_slot), tree(SS_slot), tree(fo_slot)
+            rec[:, lb, :, :K] = S.reshape(G, B_local, K)
+            rec[:, lb, :, K:2 * K] = SS.reshape(G, B_local, K)
+            rec[:, lb, :, 2 * K] = fo.reshape(G, B_local)
+        return torch.from_numpy(rec.reshape(-1, 2 * K + 4))
 
     def finish(self, mine, y_local, inv_b):
         m = mine.numpy()
@@ -76,14 +90,16 @@ class OracleOwnerBackend:
         rec[:, K + 1] = orc.loss_value(logit, y, "logits")
         return torch.from_numpy(rec)
 
-    def update(self, idx_own, rec_g, inv_b):
+    def update(self, idx_all, rec_g, inv_b):
         st = self.st
         V = orc.ftrl_weight(st["zV"], st["nV"], **HYP)
-        rows = self._rows(idx_own)
+        rows, ok = self._occ(idx_all)
         rec = rec_g.numpy()
         S, dz, loss_g = np.ascontiguousarray(rec[:, :K]), np.ascontiguousarray(rec[:, K]), rec[:, K + 1]
-        x = np.ones(rows.shape, dtype=f32)
+        x = ok.astype(f32)                                            # absent occurrences: x = 0 on the scratch row
         u, dV, dw = orc.flat_row_gradients(V, rows, x, S, dz, np.repeat(dz[:, None], K, axis=1))
+        keep = u != self.scratch
+        u, dV, dw = u[keep], dV[keep], dw[keep]
         st["zV"][u], st["nV"][u] = orc.ftrl_step(st["zV"][u], st["nV"][u], dV, **HYP)
         st["zw"][u], st["nw"][u] = orc.ftrl_step(st["zw"][u], st["nw"][u], dw, **HYP)
         st["zb"], st["nb"] = orc.ftrl_step(st["zb"], st["nb"], dz.sum(dtype=f32), **HYP)      # replicated, identical everywhere
@@ -94,11 +110,11 @@ def make_state():
     rng = np.random.default_rng(3)
     offs = np.concatenate([[0], np.cumsum(SIZES)]).astype(np.int64)
     R = int(offs[-1])
-    V = (rng.normal(size=(R, K)) * 0.3).astype(f32)
-    w = (rng.normal(size=R) * 0.3).astype(f32)
+    V = (rng.normal(size=(R + 1, K)) * 0.3).astype(f32)            # (+ the scratch row)
+    w = (rng.normal(size=R + 1) * 0.3).astype(f32)
     st = dict(zV=orc.ftrl_z_for_weight(V, **HYP), nV=np.zeros_like(V), zw=orc.ftrl_z_for_weight(w, **HYP),
               nw=np.zeros_like(w), zb=f32(0.1), nb=f32(0.0))
-    return st, offs[:-1]
+    return st, offs
 
 
 def make_batches(world):
@@ -108,41 +124,69 @@ def make_batches(world):
              (rng.uniform(size=GB) < 0.3).astype(f32)) for _ in range(STEPS)]
 
 
+WORLDS = (2, 3)
+
+
+def make_plan(world):
+    from fmx.plan import OwnerPlan
+    return OwnerPlan(SIZES, K, world, global_batch=B_LOCAL * world)
+
+
+class WholePlan:
+    """The same pieces at the same positions held by ONE rank: what `world` owners must be bit-identical to."""
+
+    def __init__(self, plan):
+        self.nb, self.sl, self.np, self.block_count = plan.nb, plan.sl, plan.np, [plan.nb]
+        self._fields = sum((plan._fields_of_block(b) for b in range(plan.nb)), [])
+
+    def owner_fields(self, g):
+        return self._fields
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from fmx.owner import FieldOwnerFM
     st, offs = make_state()
-    be = OracleOwnerBackend(st, offs, rank, world)
+    be = OracleOwnerBackend(st, offs, rank, world, make_plan(world))
     fo = FieldOwnerFM(be)
     sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL)
     losses = [float(fo.step(torch.from_numpy(idx[sl].copy()), torch.from_numpy(y[sl].copy()))[0]) for idx, y in make_batches(world)]
-    q.put((rank, losses, be.fields, {k: np.asarray(v).copy() for k, v in st.items()}))
+    q.put((rank, losses, [f for f in be.fields if f[2]], {k: np.asarray(v).copy() for k, v in st.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_owner_fields_partition_the_fields():
-    from fmx.owner import owner_fields
-    for F, k in ((39, 16), (39, 10), (10, 16), (70, 4), (5, 64), (20, 16)):
-        slots = 64 // (max(4, 1 << (k - 1).bit_length()) // 4) if k > 4 else 64
-        for world in (1, 2, 4, 8, 16):
-            if slots % world:
-                with pytest.raises(ValueError):
-                    owner_fields(F, k, world, 0)
+def test_plans_partition_the_rows():
+    """Every row has exactly one owner, every owner has rows, the positions of the pieces are distinct -- for any number of
+    columns and any world size up to the number of lane groups (powers of two or not)."""
+    from fmx.plan import OwnerPlan
+    cases = ((SIZES, 16), ([1000] * 10, 16), ([7, 3, 50], 16), ([5] * 70, 4), ([40000, 3, 9], 64), (list(range(1, 40)), 10))
+    for sizes, k in cases:
+        slots = 64 // (max(4, 1 << (k - 1).bit_length()) // 4)
+        for world in range(1, min(slots, 9) + 1):
+            if sum(sizes) < world:
                 continue
-            owned = [owner_fields(F, k, world, g) for g in range(world)]
-            assert sorted(sum(owned, [])) == list(range(F))                     # every field has exactly one owner
-            sl = slots // world
-            for g, fs in enumerate(owned):                                      # local field l is in lane group l % SL of rank g
-                assert all((f % slots) == g * sl + (l % sl) and f // slots == l // sl for l, f in enumerate(fs))
+            plan = OwnerPlan(sizes, k, world, global_batch=256 * world)
+            covered = [np.zeros(s, dtype=np.int32) for s in sizes]
+            for g in range(world):
+                fields = plan.owner_fields(g)
+                assert len(fields) == plan.block_count[g] * plan.np * plan.sl
+                assert sum(r for _, _, r in fields) >= 1, (sizes, world, g)
+                for c, b, r in fields:
+                    covered[c][b:b + r] += 1
+            assert all((c == 1).all() for c in covered), (sizes, world)
+            whole = plan.whole_fields()
+            assert sorted(f for f in whole if f[2]) == sorted(plan.pieces)
+            if world == 1:
+                assert [f for f in whole[:len(sizes)]] == [(c, 0, r) for c, r in enumerate(sizes)]     # the ordinary table
     with pytest.raises(ValueError):
-        owner_fields(39, 16, 3, 0)
+        OwnerPlan([1, 1], 16, 4)                                                 # two rows cannot be dealt over four owners
 
 
 @pytest.mark.timeout(300)
-def test_two_owners_equal_one_owner_bit_for_bit():
-    world = 2
+@pytest.mark.parametrize("world", WORLDS)
+def test_owners_equal_one_owner_bit_for_bit(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     with socket.socket() as s:
@@ -157,21 +201,20 @@ def test_two_owners_equal_one_owner_bit_for_bit():
         assert p.exitcode == 0
     from fmx.owner import FieldOwnerFM
     st, offs = make_state()
-    one = FieldOwnerFM(OracleOwnerBackend(st, offs, 0, 1))
+    one = FieldOwnerFM(OracleOwnerBackend(st, offs, 0, 1, WholePlan(make_plan(world))))
     ref_losses = [float(one.step(torch.from_numpy(idx), torch.from_numpy(y))[0]) for idx, y in make_batches(world)]
     st0, _ = make_state()
-    offs_full = np.concatenate([offs, [sum(SIZES)]])
-    seen = set()
+    owner_of = {}
     for rank, losses, fields, state in res:
         assert losses == ref_losses                                              # the same bits, not "close"
         assert state["zb"] == st["zb"] and state["nb"] == st["nb"]               # replicated bias: identical on every rank
-        for f in range(len(SIZES)):
-            rows = slice(int(offs_full[f]), int(offs_full[f + 1]))
-            for k in ("zV", "nV", "zw", "nw"):
-                if f in fields:                                                  # the owner holds the trained rows ...
-                    np.testing.assert_array_equal(state[k][rows], st[k][rows], err_msg=f"rank {rank} field {f} {k}")
-                else:                                                            # ... and nobody else ever touches them
-                    np.testing.assert_array_equal(state[k][rows], st0[k][rows], err_msg=f"rank {rank} foreign field {f} {k}")
-        seen |= set(fields)
-    assert seen == set(range(len(SIZES)))
+        mine = np.zeros(int(offs[-1]) + 1, dtype=bool)
+        for c, b, r in fields:
+            mine[int(offs[c]) + b:int(offs[c]) + b + r] = True
+            assert (c, b, r) not in owner_of
+            owner_of[(c, b, r)] = rank
+        for k in ("zV", "nV", "zw", "nw"):
+            np.testing.assert_array_equal(state[k][mine], st[k][mine], err_msg=f"rank {rank} {k}: its own rows")   # the owner holds the trained rows ...
+            np.testing.assert_array_equal(state[k][~mine], st0[k][~mine], err_msg=f"rank {rank} {k}: foreign rows")  # ... nobody else touches them
+    assert sum(r for _, _, r in owner_of) == sum(SIZES)
     assert any((st[k] != st0[k]).any() for k in ("zV", "zw"))                     # the steps did train

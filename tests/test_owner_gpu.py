@@ -1,8 +1,10 @@
-"""The field-owner multi-GPU mode through the HIP backend (fmx.owner): every additions tree of the one-GPU kernels is
-reproduced, so G owners leave BIT-IDENTICAL rows, biases and losses to fmx_fm_step on one table holding every field.
-Checked (a) with the G owners emulated in one process (the exchange done by slicing: exercises the kernels for every
-G = 1 ... 16), (b) with two processes sharing the test box's one GPU, collectives over gloo with host staging (RCCL needs
-one GPU per rank), including a Frappe-shaped 10 M-row table split over the two ranks (BASELINE configs[4]'s table)."""
+"""The field-owner multi-GPU mode through the HIP backend (fmx.owner, fmx.plan): the owners hold row-range PIECES of the index
+columns at fixed positions of the forward tree, so G owners leave BIT-IDENTICAL rows, biases and losses to fmx_fm_step on ONE
+table holding the same pieces at the same positions (OwnerPlan.table_whole) -- and that table's step meets the oracle at
+north_star's tolerance.  Checked (a) with the G owners emulated in one process (the exchange done by slicing: exercises the
+kernels for G = 1 ... 16, powers of two and not, Criteo- and Frappe-shaped), (b) with two processes sharing the test box's
+one GPU, collectives over gloo with host staging (RCCL needs one GPU per rank), including a Frappe-shaped 10 M-row table
+split over the two ranks (BASELINE configs[4]'s table)."""
 import os
 import socket
 
@@ -11,6 +13,9 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+from helpers import assert_ftrl_step_within_f64, assert_within_f64
+from oracle import fm_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
@@ -26,10 +31,15 @@ def _weights(sizes, k, seed=5):
     return (rng.normal(size=(R, k)) * 0.3).astype(np.float32), (rng.normal(size=R) * 0.3).astype(np.float32)
 
 
-def _load(t, sizes, fields, V, w):
+def _columns(sizes, V, w):
     offs = np.concatenate([[0], np.cumsum(sizes)])
-    t.load_reference([torch.from_numpy(w[offs[f]:offs[f + 1]].reshape(-1, 1)) for f in fields],
-                     [torch.from_numpy(V[offs[f]:offs[f + 1]]) for f in fields])
+    return ([torch.from_numpy(w[offs[c]:offs[c + 1]].reshape(-1, 1)) for c in range(len(sizes))],
+            [torch.from_numpy(V[offs[c]:offs[c + 1]]) for c in range(len(sizes))])
+
+
+def _load(t, sizes, V, w):
+    from fmx.plan import load_columns
+    load_columns(t, *_columns(sizes, V, w))
     t.set_bias_weight(0.25)
 
 
@@ -39,11 +49,11 @@ def _batches(sizes, GB, steps, seed=9):
              (rng.uniform(size=GB) < 0.3).astype(np.float32)) for _ in range(steps)]
 
 
-def _plain_run(fmx, sizes, k, rule, batches):
-    """The reference for every owner test: one table with every field, fmx_fm_step per global batch."""
+def _whole_run(fmx, plan, sizes, k, rule, batches):
+    """The reference for every owner test: ONE table with every piece at its position, fmx_fm_step per global batch."""
     V, w = _weights(sizes, k)
-    t = fmx.FlatTable(sizes, k, layout="ftrl" if rule == "ftrl" else "weights", ftrl=HYP)
-    _load(t, sizes, range(len(sizes)), V, w)
+    t = plan.table_whole(layout="ftrl" if rule == "ftrl" else "weights", ftrl=HYP)
+    _load(t, sizes, V, w)
     eng = fmx.FMEngine(t, max_batch=batches[0][0].shape[0])
     hyp = fmx.Hyper(**HYP)
     losses = []
@@ -55,81 +65,177 @@ def _plain_run(fmx, sizes, k, rule, batches):
     return t, losses
 
 
-def _field_rows(t, sizes_local):
-    offs = np.concatenate([[0], np.cumsum(sizes_local)])
-    rows = t.rows.cpu().numpy()
-    return [rows[offs[i]:offs[i + 1]] for i in range(len(sizes_local))]
+def _pieces(t):
+    from fmx.plan import export_columns
+    return {key: rows.numpy() for key, rows in export_columns(t, None).items()}
 
 
-@pytest.mark.parametrize("sizes,k,B,rule,G", [(CRITEO_SIZES, 16, 1024, "ftrl", 1), (CRITEO_SIZES, 16, 1024, "ftrl", 2),
-                                              (CRITEO_SIZES, 16, 512, "ftrl", 8), (CRITEO_SIZES, 10, 256, "signadam", 4),
-                                              (CRITEO_SIZES, 16, 128, "sgd", 16), ([7, 3, 50, 2, 9, 1000, 4, 4, 30] * 8, 4, 96, "ftrl", 4),
-                                              ([5, 40, 3, 700, 2, 11], 32, 64, "sgd", 2)])
-def test_emulated_owners_equal_the_one_table_step(sizes, k, B, rule, G):
+def _emulate(fmx, plan, sizes, k, B, rule, batches):
     """G owners in one process (each with its shard of the table), the all-gathers / all-to-all done by slicing."""
-    import fmx
-    from fmx.owner import HipOwnerBackend, owner_fields
-    GB, steps = B * G, 3
-    batches = _batches(sizes, GB, steps)
-    t_ref, ref_losses = _plain_run(fmx, sizes, k, rule, batches)
+    from fmx.owner import HipOwnerBackend
+    G, GB = plan.world, batches[0][0].shape[0]
     V, w = _weights(sizes, k)
     hyp = fmx.Hyper(**HYP)
     owners = []
     for g in range(G):
-        be = HipOwnerBackend(sizes, k, hyp, rule, "logits", g, G, ftrl=HYP, max_local_batch=B)
-        _load(be.table, sizes, be.fields, V, w)
+        be = HipOwnerBackend(sizes, k, hyp, rule, "logits", g, G, ftrl=HYP, max_local_batch=B, plan=plan)
+        _load(be.table, sizes, V, w)
         owners.append(be)
-    assert sorted(sum((be.fields for be in owners), [])) == list(range(len(sizes)))
-    inv_b = 1.0 / GB
-    for step, (idx, y) in enumerate(batches):
+    inv_b, REC = 1.0 / GB, 2 * owners[0].kp + 4
+    all_losses = []
+    for idx, y in batches:
         idx_all = torch.from_numpy(idx).cuda()
         y_all = torch.from_numpy(y).cuda()
-        own = [be.select(idx_all) for be in owners]
-        parts = [be.partial_forward(o).clone() for be, o in zip(owners, own)]               # [GB, 2 kp + 4] per owner
+        parts = [be.partial_forward(idx_all, B).clone().view(G, be.nlb, B, REC) for be in owners]      # destination-major per owner
         recs = []
-        for r, be in enumerate(owners):                                                     # all-to-all: rank r's samples
-            mine = torch.stack([p[r * B:(r + 1) * B] for p in parts]).contiguous()
+        for r, be in enumerate(owners):                                                     # all-to-all: rank r's samples, block order
+            mine = torch.cat([p[r] for p in parts]).contiguous()
+            assert mine.shape[0] == plan.nb
             recs.append(be.finish(mine, y_all[r * B:(r + 1) * B].contiguous(), inv_b).clone())
         rec_g = torch.cat(recs).contiguous()                                                # all-gather
-        losses = [float(be.update(o, rec_g, inv_b)[0]) for be, o in zip(owners, own)]
-        assert all(l == ref_losses[step] for l in losses), (losses, ref_losses[step])
+        all_losses.append([float(be.update(idx_all, rec_g, inv_b)[0]) for be in owners])
     torch.cuda.synchronize()
-    ref_fields = _field_rows(t_ref, sizes)
     for be in owners:
-        be.e.check_error_flag()
-        for rows, f in zip(_field_rows(be.table, [sizes[f] for f in be.fields]), be.fields):
-            np.testing.assert_array_equal(rows, ref_fields[f], err_msg=f"owner {be.rank} field {f}")
-        np.testing.assert_array_equal(be.table.bias.cpu().numpy(), t_ref.bias.cpu().numpy())
+        be.check_error_flag()
+    return owners, all_losses
 
 
-def test_an_owner_without_fields_is_refused():
+FRAPPE_SMALL = [2000] * 10       # Frappe-shaped: 10 one-hot columns (BASELINE configs[4]), fewer columns than lane groups
+
+
+@pytest.mark.parametrize("sizes,k,B,rule,G", [(CRITEO_SIZES, 16, 1024, "ftrl", 1), (CRITEO_SIZES, 16, 1024, "ftrl", 2),
+                                              (CRITEO_SIZES, 16, 512, "ftrl", 8), (CRITEO_SIZES, 10, 256, "signadam", 4),
+                                              (CRITEO_SIZES, 16, 128, "sgd", 16), (CRITEO_SIZES, 16, 256, "ftrl", 3),
+                                              (CRITEO_SIZES, 16, 128, "ftrl", 6), (FRAPPE_SMALL, 16, 256, "ftrl", 4),
+                                              (FRAPPE_SMALL, 16, 128, "ftrl", 8), ([7, 3, 50], 16, 64, "sgd", 4),
+                                              ([7, 3, 50, 2, 9, 1000, 4, 4, 30] * 8, 4, 96, "ftrl", 4),
+                                              ([5, 40, 3, 700, 2, 11], 32, 64, "sgd", 2)])
+def test_emulated_owners_equal_the_one_table_step(sizes, k, B, rule, G):
     import fmx
-    from fmx.owner import HipOwnerBackend
-    with pytest.raises(ValueError, match="would own no field"):
-        HipOwnerBackend([7, 3, 50], 4, fmx.Hyper(**HYP), "sgd", "logits", 1, 4)      # 3 fields in 64 lane groups: rank 1 of 4 gets none
+    from fmx.plan import OwnerPlan
+    GB, steps = B * G, 3
+    plan = OwnerPlan(sizes, k, G, global_batch=GB)
+    rows = plan.rows_per_owner()
+    assert sum(rows) == sum(sizes) and min(rows) >= 1                                       # every row has one owner, every owner has rows
+    batches = _batches(sizes, GB, steps)
+    t_ref, ref_losses = _whole_run(fmx, plan, sizes, k, rule, batches)
+    owners, losses = _emulate(fmx, plan, sizes, k, B, rule, batches)
+    for step, ls in enumerate(losses):
+        assert all(l == ref_losses[step] for l in ls), (ls, ref_losses[step])
+    ref = _pieces(t_ref)
+    seen = set()
+    for be in owners:
+        mine = _pieces(be.table)
+        for key, r in mine.items():
+            np.testing.assert_array_equal(r, ref[key], err_msg=f"owner {be.rank} piece {key}")
+        seen |= set(mine)
+        np.testing.assert_array_equal(be.table.bias.cpu().numpy(), t_ref.bias.cpu().numpy())
+    assert seen == set(ref)
+
+
+def test_one_owner_is_the_ordinary_table():
+    """world == 1: the plan places column f at position f -- the ordinary (unmapped) table, the old bits."""
+    import fmx
+    from fmx.plan import OwnerPlan
+    sizes, k, B = CRITEO_SIZES, 16, 1024
+    plan = OwnerPlan(sizes, k, 1)
+    t = plan.table_whole(layout="ftrl", ftrl=HYP)
+    assert not t.mapped and t.feature_sizes == sizes
+
+
+@pytest.mark.parametrize("sizes,G,B", [(CRITEO_SIZES, 8, 512), (FRAPPE_SMALL, 8, 512)])
+def test_the_whole_table_step_meets_the_oracle(sizes, G, B):
+    """The one-table equivalent of G owners (pieces at their positions: another order of the forward's additions than the
+    ordinary table) against the float64 step at north_star's 1e-5 + the derived fp32 floor, touched rows and untouched ones;
+    then the owners against it bit for bit.  So the owners' rows meet the oracle, not only each other."""
+    import fmx
+    from fmx.plan import OwnerPlan
+    k, GB = 16, B * G
+    plan = OwnerPlan(sizes, k, G, global_batch=GB)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    V, w = _weights(sizes, k)
+    h = dict(alpha=HYP["alpha"], beta=HYP["beta"], l1=HYP["l1"], l2=HYP["l2"])
+    batches = _batches(sizes, GB, 1)
+    idx, y = batches[0]
+    t_ref, ref_losses = _whole_run(fmx, plan, sizes, k, "ftrl", batches)
+    # the same start in the oracle's layout (column-major rows): n = 0, z reproducing the weights, bias 0.25
+    st0 = dict(zV=orc.ftrl_z_for_weight(V, **h), nV=np.zeros_like(V), zw=orc.ftrl_z_for_weight(w, **h), nw=np.zeros_like(w),
+               zb=np.float32(orc.ftrl_z_for_weight(np.float32(0.25), **h)), nb=np.float32(0.0))
+    rows = idx.astype(np.int64) + offs[:-1][None, :]
+    ref = orc.flat_fm_step_f64(st0, rows, np.ones(idx.shape, np.float32), y, "logits", "ftrl", h)
+    assert_within_f64(ref_losses[0], ref["loss"], ref["floor"]["loss"], "loss")
+    # gather the table's pieces back into the oracle's row order
+    zo, kp = t_ref.z_offset, t_ref.kp
+    got = dict(zV=np.zeros_like(V), nV=np.zeros_like(V), zw=np.zeros_like(w), nw=np.zeros_like(w))
+    for (c, b, r), pr in _pieces(t_ref).items():
+        lo = int(offs[c]) + b
+        got["zV"][lo:lo + r], got["nV"][lo:lo + r] = pr[:, zo:zo + k], pr[:, zo + kp:zo + kp + k]
+        got["zw"][lo:lo + r], got["nw"][lo:lo + r] = pr[:, kp + 1], pr[:, kp + 2]
+    got["zb"], got["nb"] = t_ref.bias[0].item(), t_ref.bias[1].item()
+    assert_ftrl_step_within_f64(got, ref)
+    owners, losses = _emulate(fmx, plan, sizes, k, B, "ftrl", batches)
+    assert all(l == ref_losses[0] for l in losses[0])
+    whole = _pieces(t_ref)
+    for be in owners:
+        for key, r in _pieces(be.table).items():
+            np.testing.assert_array_equal(r, whole[key], err_msg=f"owner {be.rank} piece {key}")
+
+
+def test_criteo_ownership_is_balanced_at_eight_ranks():
+    from fmx.plan import OwnerPlan
+    plan = OwnerPlan(CRITEO_SIZES, 16, 8, global_batch=8 * 4096)
+    rows = plan.rows_per_owner()
+    assert max(rows) <= 2 * min(rows), rows                                                # HBM footprint within 2x
+    occ = [float(l[1]) for l in plan.rank_load]
+    assert max(occ) <= 1.5 * min(occ), occ                                                 # expected update work within 1.5x
+    plan10 = OwnerPlan([1_000_000] * 10, 16, 8, global_batch=8 * 1024)                     # configs[4]: 10 columns over 8 ranks
+    assert min(plan10.rows_per_owner()) >= 1_000_000 and max(plan10.rows_per_owner()) <= 1_500_000
+
+
+def test_a_stale_workspace_is_refused():
+    """A workspace sized before the table's large pieces were split for a larger batch is too small afterwards at EVERY batch
+    size: the C side checks the byte count and refuses (it used to write out of bounds)."""
+    import fmx
+    sizes, k = [300000, 50, 7], 16
+    t = fmx.FlatTable(sizes, k, layout="weights")
+    eng = fmx.FMEngine(t, max_batch=4096)
+    old = eng.new_workspace(4096)
+    t.sort_cap_override = 100000               # as a growth to a much larger batch would: the 300,000-row field becomes three pieces
+    eng._alloc(4096)
+    idx = torch.zeros((4096, 3), dtype=torch.int32, device="cuda")
+    with pytest.raises(fmx._lib.FmxError, match="workspace of"):
+        eng.sort(idx, workspace=old)
+    eng.sort(idx)                              # the engine's own workspace was rebuilt with the table
+    torch.cuda.synchronize()
 
 
 def test_owner_class_single_rank_with_prefetch_equals_plain_steps():
     import fmx
     from fmx.owner import FieldOwnerFM, HipOwnerBackend
+    from fmx.plan import OwnerPlan
     sizes, k, B, steps = CRITEO_SIZES, 16, 4096, 5
     batches = _batches(sizes, B, steps)
-    t_ref, ref_losses = _plain_run(fmx, sizes, k, "ftrl", batches)
+    plan = OwnerPlan(sizes, k, 1)
+    t_ref, ref_losses = _whole_run(fmx, plan, sizes, k, "ftrl", batches)
     V, w = _weights(sizes, k)
     be = HipOwnerBackend(sizes, k, fmx.Hyper(**HYP), "ftrl", "logits", 0, 1, ftrl=HYP, max_local_batch=B)
-    _load(be.table, sizes, be.fields, V, w)
+    _load(be.table, sizes, V, w)
     fo = FieldOwnerFM(be)
     data = [(torch.from_numpy(i).cuda(), torch.from_numpy(y).cuda()) for i, y in batches]
     work = torch.cuda.Stream()
     losses = []
     with torch.cuda.stream(work):
         tokens = {0: fo.prefetch(data[0][0]), 1: fo.prefetch(data[1][0])}
+        spare = fo.prefetch(data[2][0])                                                     # a token that is given back unused
+        fo.cancel(spare)
         for i, (idx_d, y_d) in enumerate(data):
             losses.append(fo.step(idx_d, y_d, tokens.pop(i, None)).clone())
             if i + 2 < steps and i != 1:                                                    # step 3 runs with nothing prepared
                 tokens[i + 2] = fo.prefetch(data[i + 2][0])
+                assert tokens[i + 2] is not None
     torch.cuda.synchronize()
-    be.e.check_error_flag()
+    fo.check_error_flag()
+    assert not fo._pref
     assert [float(l[0]) for l in losses] == ref_losses
     np.testing.assert_array_equal(be.table.rows.cpu().numpy(), t_ref.rows.cpu().numpy())
     np.testing.assert_array_equal(be.table.bias.cpu().numpy(), t_ref.bias.cpu().numpy())
@@ -139,43 +245,83 @@ def test_owner_class_single_rank_with_prefetch_equals_plain_steps():
 FRAPPE_SIZES = [1_000_000] * 10                    # Frappe-shaped: 10 one-hot fields, 10 M rows in all (BASELINE configs[4])
 
 
-def _owner_run(rank, world, sizes, k, B, steps, frappe):
+def _seed_frappe(fmx, t, k):
+    """A 2.5 GB table: seeded on the device, piece by piece (the same numbers for a row wherever it lives)."""
+    zo = t.z_offset
+    for f, (c, b, r) in enumerate(t.plan_fields):
+        if not r:
+            continue
+        g = torch.Generator(device="cuda").manual_seed(100 + c)
+        Vc = torch.randn((FRAPPE_SIZES[c], k), generator=g, device="cuda") * 0.3
+        lo = int(t.offsets_host[f])
+        t.rows[lo:lo + r, :k] = Vc[b:b + r]
+        t.rows[lo:lo + r, zo:zo + k] = fmx.table.ftrl_z_for_weight_torch(Vc[b:b + r], t.ftrl)
+        del Vc
+
+
+def _touched(idx_batches, sizes):
+    """Per column the sorted local indices any of the batches touches."""
+    return [np.unique(np.concatenate([i[:, c] for i, _ in idx_batches])) for c in range(len(sizes))]
+
+
+def _rows_of(t, touched):
+    """{(column, local index): row} of the touched rows this table holds."""
+    out, rows = {}, None
+    for f, (c, b, r) in enumerate(t.plan_fields):
+        if not r:
+            continue
+        sel = touched[c][(touched[c] >= b) & (touched[c] < b + r)]
+        lo = int(t.offsets_host[f])
+        got = t.rows[torch.from_numpy(lo + (sel - b)).cuda()].cpu().numpy()
+        for i, li in enumerate(sel):
+            out[(c, int(li))] = got[i]
+    return out
+
+
+def _owner_run(rank, world, sizes, k, B, steps, frappe, whole=False):
     import fmx
     from fmx.owner import FieldOwnerFM, HipOwnerBackend
+    from fmx.plan import OwnerPlan
     hyp = fmx.Hyper(**HYP)
-    be = HipOwnerBackend(sizes, k, hyp, "ftrl", "logits", rank, world, ftrl=HYP, max_local_batch=B)
-    if frappe:                                      # a 2.5 GB table: seeded on the device, field by field (the same numbers on every rank)
-        offs = np.concatenate([[0], np.cumsum([sizes[f] for f in be.fields])])
-        for l, f in enumerate(be.fields):
-            g = torch.Generator(device="cuda").manual_seed(100 + f)
-            Vf = torch.randn((sizes[f], k), generator=g, device="cuda") * 0.3
-            be.table.rows[offs[l]:offs[l + 1], :k] = Vf
-            zo = be.table.z_offset
-            be.table.rows[offs[l]:offs[l + 1], zo:zo + k] = fmx.table.ftrl_z_for_weight_torch(Vf, be.table.ftrl)
+    batches = _batches(sizes, B * world, steps)
+    plan = OwnerPlan(sizes, k, world, global_batch=B * world)
+    if whole:                                       # the one-table equivalent of `world` owners, stepped by fmx_fm_step
+        t = plan.table_whole(layout="ftrl", ftrl=HYP)
+        eng = fmx.FMEngine(t, max_batch=B * world)
     else:
-        V, w = _weights(sizes, k)
-        _load(be.table, sizes, be.fields, V, w)
-    fo = FieldOwnerFM(be)
-    sl = slice(rank * B, (rank + 1) * B)
-    data = [(torch.from_numpy(i[sl].copy()).cuda(), torch.from_numpy(y[sl].copy()).cuda()) for i, y in _batches(sizes, B * world, steps)]
-    losses, tok = [], fo.prefetch(data[0][0])
-    for i, (idx_d, y_d) in enumerate(data):
-        losses.append(float(fo.step(idx_d, y_d, tok)[0]))
-        tok = fo.prefetch(data[i + 1][0]) if i + 1 < steps else None
-    torch.cuda.synchronize()
-    be.e.check_error_flag()
-    if frappe:                                      # digest: the touched rows are a tiny part of 2.5 GB
-        r = be.table.rows
-        digest = [float(r[:, :k].double().sum()), float(r[:, be.table.z_offset:].double().abs().sum()), float((r[:, k + 1] != 0).sum())]
-        return losses, be.fields, digest, be.table.bias.cpu().numpy()
-    return losses, be.fields, _field_rows(be.table, [sizes[f] for f in be.fields]), be.table.bias.cpu().numpy()
+        be = HipOwnerBackend(sizes, k, hyp, "ftrl", "logits", rank, world, ftrl=HYP, max_local_batch=B, plan=plan)
+        t = be.table
+    if frappe:
+        _seed_frappe(fmx, t, k)
+    else:
+        _load(t, sizes, *_weights(sizes, k))
+    losses = []
+    if whole:
+        for idx, y in batches:
+            idx_d, _, y_d = eng.to_device(idx, None, y)
+            eng.step(hyp, "ftrl", "logits", idx_d, None, y_d)
+            losses.append(float(eng.loss_out.item()))
+        eng.check_error_flag()
+    else:
+        fo = FieldOwnerFM(be)
+        sl = slice(rank * B, (rank + 1) * B)
+        data = [(torch.from_numpy(i[sl].copy()).cuda(), torch.from_numpy(y[sl].copy()).cuda()) for i, y in batches]
+        tok = fo.prefetch(data[0][0])
+        for i, (idx_d, y_d) in enumerate(data):
+            losses.append(float(fo.step(idx_d, y_d, tok)[0]))
+            tok = fo.prefetch(data[i + 1][0]) if i + 1 < steps else None
+        torch.cuda.synchronize()
+        fo.check_error_flag()
+    if frappe:                                      # the touched rows (a tiny part of 2.5 GB), each under its (column, index)
+        return losses, _rows_of(t, _touched(batches, sizes)), t.bias.cpu().numpy()
+    return losses, _pieces(t), t.bias.cpu().numpy()
 
 
 def _worker(rank, world, port, q, args):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path[:0] = [root, os.path.join(root, "fm-for-online-recommendation_amd")]
+    sys.path[:0] = [root, os.path.join(root, "fm-for-online-recommendation_amd"), os.path.join(root, "tests")]
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     q.put((rank,) + _owner_run(rank, world, *args))
@@ -200,36 +346,61 @@ def _spawn(world, args):
 
 
 @pytest.mark.timeout(600)
-def test_two_owner_processes_equal_the_one_table_step():
-    import fmx
+@pytest.mark.parametrize("world", [2, 3])
+def test_owner_processes_equal_the_one_table_step(world):
     sizes, k, B, steps = CRITEO_SIZES, 16, 512, 4
-    res = _spawn(2, (sizes, k, B, steps, False))
-    t_ref, ref_losses = _plain_run(fmx, sizes, k, "ftrl", _batches(sizes, B * 2, steps))
-    ref_fields = _field_rows(t_ref, sizes)
-    for rank, losses, fields, rows, bias in res:
+    res = _spawn(world, (sizes, k, B, steps, False))
+    ref_losses, ref, ref_bias = _owner_run(0, world, sizes, k, B, steps, False, whole=True)
+    seen = set()
+    for rank, losses, pieces, bias in res:
         assert losses == ref_losses
-        for r, f in zip(rows, fields):
-            np.testing.assert_array_equal(r, ref_fields[f], err_msg=f"rank {rank} field {f}")
-        np.testing.assert_array_equal(bias, t_ref.bias.cpu().numpy())
-    assert sorted(res[0][2] + res[1][2]) == list(range(len(sizes)))
+        for key, r in pieces.items():
+            np.testing.assert_array_equal(r, ref[key], err_msg=f"rank {rank} piece {key}")
+        seen |= set(pieces)
+        np.testing.assert_array_equal(bias, ref_bias)
+    assert seen == set(ref)
 
 
 @pytest.mark.timeout(900)
 def test_frappe_shaped_10m_row_table_split_over_two_owners():
     """BASELINE configs[4]'s table: 10 M rows (2.5 GB in the FTRL layout) -- here TRAINED (forward + fused FTRL update), split
-    over two ranks by lane group (8 and 2 of the 10 fields: ownership follows the forward wavefront's 16 lane groups, so
-    fewer fields than groups split unevenly); against one process holding all of it (the same seeded rows)."""
+    over two ranks (5 M rows each); against ONE process holding all of it at the same positions: every touched ROW compared bit
+    for bit (not a digest), and those rows against the oracle's float64 step at 1e-5 + the fp32 floor."""
     sizes, k, B, steps = FRAPPE_SIZES, 16, 1024, 3
     res = _spawn(2, (sizes, k, B, steps, True))
-    one = _owner_run(0, 1, sizes, k, B * 2, steps, True)                          # world 1: every field on one rank, global batches
-    for rank, losses, fields, digest, bias in res:
-        assert losses == one[0]
-        np.testing.assert_array_equal(bias, one[3])
-        assert len(fields) == (8, 2)[rank]      # lane groups 0-7 | 8-15 of the forward wavefront: fields 0-7 | 8-9 (10 fields, 16 groups)
-    # the digests of the two shards add up to the one table's (sums over disjoint row sets; float64 accumulation)
-    for j in range(3):
-        tot = res[0][3][j] + res[1][3][j]
-        assert abs(tot - one[2][j]) <= 1e-9 * max(1.0, abs(one[2][j])), (j, tot, one[2][j])
+    one_losses, one_rows, one_bias = _owner_run(0, 2, sizes, k, B, steps, True, whole=True)
+    got = {}
+    for rank, losses, rows, bias in res:
+        assert losses == one_losses
+        np.testing.assert_array_equal(bias, one_bias)
+        assert 0 < len(rows) < len(one_rows)
+        got.update(rows)
+    assert set(got) == set(one_rows)
+    for key, r in one_rows.items():
+        np.testing.assert_array_equal(got[key], r, err_msg=f"row {key}")
+    # ---- the touched rows of the FIRST step against the oracle (float64 step over just those rows' state) ----
+    one1_losses, rows1, bias1 = _owner_run(0, 2, sizes, k, B, 1, True, whole=True)
+    idx, y = _batches(sizes, B * 2, 1)[0]
+    keys = sorted(rows1)                                                                    # (column, index) of every touched row
+    pos = {key: i for i, key in enumerate(keys)}
+    h = dict(alpha=HYP["alpha"], beta=HYP["beta"], l1=HYP["l1"], l2=HYP["l2"])
+    V0 = np.zeros((len(keys), k), np.float32)
+    for c in range(len(sizes)):                                                             # the seeded start of exactly those rows
+        g = torch.Generator(device="cuda").manual_seed(100 + c)
+        Vc = (torch.randn((sizes[c], k), generator=g, device="cuda") * 0.3).cpu().numpy()
+        for (cc, li), i in pos.items():
+            if cc == c:
+                V0[i] = Vc[li]
+    st0 = dict(zV=orc.ftrl_z_for_weight(V0, **h), nV=np.zeros_like(V0), zw=np.zeros(len(keys), np.float32), nw=np.zeros(len(keys), np.float32),
+               zb=np.float32(0.0), nb=np.float32(0.0))
+    rows = np.array([[pos[(c, int(idx[b, c]))] for c in range(len(sizes))] for b in range(idx.shape[0])], dtype=np.int64)
+    ref = orc.flat_fm_step_f64(st0, rows, np.ones(idx.shape, np.float32), y, "logits", "ftrl", h)
+    assert_within_f64(one1_losses[0], ref["loss"], ref["floor"]["loss"], "loss")
+    kp, zo = 16, 32
+    hip = dict(zV=np.stack([rows1[key][zo:zo + k] for key in keys]), nV=np.stack([rows1[key][zo + kp:zo + kp + k] for key in keys]),
+               zw=np.array([rows1[key][kp + 1] for key in keys]), nw=np.array([rows1[key][kp + 2] for key in keys]),
+               zb=float(bias1[0]), nb=float(bias1[1]))
+    assert_ftrl_step_within_f64(hip, ref)
 
 
 def test_rccl_collectives_of_a_step_with_one_rank():

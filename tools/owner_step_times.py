@@ -25,33 +25,28 @@ def timed(fn, n=40):
 
 for G in (1, 2, 4, 8):
     GB = G * B
-    be = HipOwnerBackend(bench.CRITEO_SIZES, 16, hyper, "ftrl", "logits", 0, G, ftrl=bench.HYPER, max_local_batch=B)
-    w0 = torch.randn((be.table.n_rows, 16), device=dev) * 0.01
-    be.table.rows[:, :16] = w0
-    be.table.rows[:, be.table.z_offset:be.table.z_offset + 16] = fmx.table.ftrl_z_for_weight_torch(w0, be.table.ftrl)
-    cap = be.max_global_batch
-    n_sub = 1
-    while GB // n_sub > cap:
-        n_sub *= 2
-    GBs = GB // n_sub
-    idx_np, y_np = bench.synth_pool(4, GBs, bench.CRITEO_SIZES, 7)
-    idx_all = torch.from_numpy(idx_np).to(dev)
-    y = torch.from_numpy(y_np[0][:B // n_sub].copy()).to(dev)
-    own = [be.select(idx_all[j]) for j in range(4)]
-    t_sel = timed(lambda: be.select(idx_all[0]))
-    t_sort = timed(lambda: be.start_sort(own[0], 0, stream=work))
-    t_part = timed(lambda: be.partial_forward(own[1], stream=work))
-    parts = be.partial_forward(own[1])
-    mine = torch.stack([parts[:B // n_sub]] * G).contiguous()
-    t_fin = timed(lambda: be.finish(mine, y, 1.0 / GBs, stream=work))
-    rec = be.finish(mine, y, 1.0 / GBs)
-    rec_g = torch.cat([rec] * G).contiguous()
-    be.start_sort(own[1], 1)
-    t_upd = timed(lambda: be.update(own[1], rec_g, 1.0 / GBs, 1, stream=work))
-    print(f"G={G}: {len(be.fields)} fields on rank 0, global batch {GB} as {n_sub} exact step(s) of {GBs}: per exact step "
-          f"select {t_sel:.1f}  sort {t_sort:.1f} (ahead of time)  partial fwd {t_part:.1f}  finish {t_fin:.1f}  update {t_upd:.1f} us "
-          f"-> on the critical path {n_sub * (t_part + t_fin + t_upd):.1f} us of kernels per step of {GB} samples", flush=True)
-    del be
+    rows, tot = [], {}
+    for rank in sorted({0, G - 1}):                 # the first and the last rank's shard (the plan balances them: fmx/plan.py)
+        be = HipOwnerBackend(bench.CRITEO_SIZES, 16, hyper, "ftrl", "logits", rank, G, ftrl=bench.HYPER, max_local_batch=B)
+        w0 = torch.randn((be.table.n_rows, 16), device=dev) * 0.01
+        be.table.rows[:, :16] = w0
+        be.table.rows[:, be.table.z_offset:be.table.z_offset + 16] = fmx.table.ftrl_z_for_weight_torch(w0, be.table.ftrl)
+        idx_np, y_np = bench.synth_pool(4, GB, bench.CRITEO_SIZES, 7)
+        idx_all = torch.from_numpy(idx_np).to(dev)
+        y = torch.from_numpy(y_np[0][:B].copy()).to(dev)
+        t_sort = timed(lambda: be.start_sort(idx_all[0], 0, stream=work))
+        t_part = timed(lambda: be.partial_forward(idx_all[1], B, stream=work))
+        parts = be.partial_forward(idx_all[1], B).view(G, be.nlb, B, -1)
+        mine = torch.cat([parts[0]] * (be.nb // be.nlb)).contiguous()[:be.nb].contiguous()
+        t_fin = timed(lambda: be.finish(mine, y, 1.0 / GB, stream=work))
+        rec = be.finish(mine, y, 1.0 / GB)
+        rec_g = torch.cat([rec] * G).contiguous()
+        be.start_sort(idx_all[1], 1)
+        t_upd = timed(lambda: be.update(idx_all[1], rec_g, 1.0 / GB, 1, stream=work))
+        n_pieces = sum(1 for f in be.fields if f[2])
+        print(f"G={G} rank {rank}: {n_pieces} pieces, {be.table.n_rows} rows; global batch {GB}: sort {t_sort:.1f} (ahead of time)  "
+              f"partial fwd {t_part:.1f}  finish {t_fin:.1f}  update {t_upd:.1f} us -> on the critical path {t_part + t_fin + t_upd:.1f} us of kernels", flush=True)
+        del be
 
 be = HipOwnerBackend(bench.CRITEO_SIZES, 16, hyper, "ftrl", "logits", 0, 1, ftrl=bench.HYPER, max_local_batch=B)
 fo = FieldOwnerFM(be)
