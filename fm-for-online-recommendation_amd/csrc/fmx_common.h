@@ -42,6 +42,20 @@ struct Tune {
                          // Identical lists either way
 };
 Tune &tune();
+
+// ---- the library's RCCL communicator for the field-owner step (fmx_comm.hip) ----
+constexpr int FMX_COMM_SLOTS = 4;  // batches whose indices may be gathered + sorted ahead of their step
+struct Comm {
+  int rank = 0, world = 1, n_blocks = 1;
+  bool force = false;            // issue the collectives even with one rank (tests: the RCCL calls of a step on a one-GPU box)
+  int block_count[FMX_COMM_MAX_WORLD] = {0}, block_first[FMX_COMM_MAX_WORLD] = {0};  // tree blocks per rank (fmx/plan.py)
+  void *main = nullptr, *pf = nullptr;  // ncclComm_t of the step's stream / of the prefetch stream; null: one rank, nothing to exchange
+  hipStream_t pf_stream = nullptr;      // the prefetch stream (library-owned)
+  hipEvent_t fork = nullptr, ready[FMX_COMM_SLOTS] = {nullptr}, free_[FMX_COMM_SLOTS] = {nullptr};
+  bool used[FMX_COMM_SLOTS] = {false};  // free_[s] has been recorded at least once
+};
+int comm_all_gather(Comm *c, int which, const void *send, void *recv, size_t count, hipStream_t st);
+int comm_exchange_blocks(Comm *c, const float *send, float *recv, size_t per, hipStream_t st);
 }  // namespace fmxd
 using namespace fmxd;
 

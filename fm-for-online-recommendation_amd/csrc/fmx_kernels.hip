@@ -458,7 +458,8 @@ struct UpdArgs {
   const int32_t *cols;  // sort field -> field, or null; fcols: field -> column of xv, or null; Fx: columns of xv
   const int32_t *fcols;
   int32_t Fx;
-  uint32_t seq;      // INL: launch sequence number tagging the tile meta words of this launch
+  float *red;        // [16][4] partial (sum dlogit, sum loss, launch sequence, -) of the batch slices (B > RED_SLICE)
+  uint32_t seq;      // launch sequence number tagging the tile meta words (INL) and the slice partials of this launch
   int32_t *error;    // INL: set to 2 if a hand-off wait ran into its bound
   float inv_b;
 };
@@ -469,31 +470,90 @@ constexpr int LEAD_NONE = 0, LEAD_CLOSES = 1, LEAD_THROUGH = 2;
 __device__ __forceinline__ void st16(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 __device__ __forceinline__ void st4(float *p, float v) { *p = v; }
 
+// The bias gradient (sum of dlogit over the batch) and the mean loss.  The batch is cut into slices of RED_SLICE samples, one
+// workgroup each (the first workgroups of the launch): with the samples' (S, dlogit, loss) records gathered from G ranks the
+// values lie 80 bytes apart, one 64-byte request each, and ONE workgroup walking 2 x 32,768 of them was the longest path of
+// the launch by far (47-53 us of the update at 8 x 4,096 samples against 13 at 4,096).  One slice (B <= RED_SLICE): the sum
+// and the update in place, as before.  Several: every slice's workgroup leaves (sum dlogit, sum loss, launch sequence) as ONE
+// 16-byte write-through granule; the first workgroup polls the others' granules until they carry this launch's sequence number
+// (data and tag in one granule: no ordering needed; they belong to workgroups dispatched right behind it, which wait on
+// nothing), adds the partials in slice order and applies the update -- or, without the in-launch hand-off, k_fm_fixup's
+// last workgroup does that.  The order of the additions depends on the batch size alone: every mode gives the same bits.
+constexpr int RED_SLICE = 4096;
+__host__ __device__ inline int red_slices(int B) { return (B + RED_SLICE - 1) / RED_SLICE; }
+
 template <int LAYOUT, int RULE>
-__device__ void bias_and_loss(const UpdArgs &a) {
-  __shared__ float sm[256];
-  const float db = block_sum(a.dz_first, a.B, a.ld1, sm);
-  float ls = 0.f;
-  if (a.loss_b && a.loss_out) ls = block_sum(a.loss_b, a.B, a.ld1, sm);
-  if (threadIdx.x == 0) {
-    if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
-      st4(a.bias, apply_rule<RULE>(a.bias[0], db, a.h));
-    } else {
-      float z = a.bias[0], n = a.bias[1];
-      const float w = ftrl_w(z, n, a.h);
-      ftrl_upd(z, n, w, db, a.h);
-      st4(a.bias, z);
-      st4(a.bias + 1, n);
-    }
-    if (a.loss_b && a.loss_out) {
-      int i = 0;
-      if (a.step_counter) {
-        i = *a.step_counter;
-        *a.step_counter = i + 1;
-      }
-      a.loss_out[i] = ls * a.inv_b;
-    }
+__device__ __forceinline__ void apply_bias_and_loss(const UpdArgs &a, float db, float ls) {
+  if (LAYOUT == FMX_LAYOUT_WEIGHTS) {
+    st4(a.bias, apply_rule<RULE>(a.bias[0], db, a.h));
+  } else {
+    float z = a.bias[0], n = a.bias[1];
+    const float w = ftrl_w(z, n, a.h);
+    ftrl_upd(z, n, w, db, a.h);
+    st4(a.bias, z);
+    st4(a.bias + 1, n);
   }
+  if (a.loss_b && a.loss_out) {
+    int i = 0;
+    if (a.step_counter) {
+      i = *a.step_counter;
+      *a.step_counter = i + 1;
+    }
+    a.loss_out[i] = ls * a.inv_b;
+  }
+}
+
+// the partials of all R slices added in slice order (thread 0 of the calling workgroup applies them)
+template <int LAYOUT, int RULE>
+__device__ void finish_bias_and_loss(const UpdArgs &a, int R, bool poll) {
+  __shared__ float part[2 * 16];
+  const int t = threadIdx.x;
+  bool failed = false;
+  if (t < R) {
+    const v4f *src = reinterpret_cast<const v4f *>(a.red) + t;
+    v4f g = {0.f, 0.f, 0.f, 0.f};
+    if (poll) {
+      for (int spin = 0;; ++spin) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(g) : "v"(src) : "memory");
+        if (__float_as_uint(g.z) == a.seq) break;
+        if (spin >= (1 << 20)) {
+          failed = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    } else {
+      g = *src;
+    }
+    part[2 * t] = g.x;
+    part[2 * t + 1] = g.y;
+  }
+  if (failed && a.error) *a.error = 2;
+  __syncthreads();
+  if (t == 0) {
+    float db = 0.f, ls = 0.f;
+    for (int r = 0; r < R; ++r) {
+      db += part[2 * r];
+      ls += part[2 * r + 1];
+    }
+    apply_bias_and_loss<LAYOUT, RULE>(a, db, ls);
+  }
+}
+
+template <int LAYOUT, int RULE, bool INL>
+__device__ void bias_and_loss(const UpdArgs &a, int r) {
+  __shared__ float sm[256];
+  const int R = red_slices(a.B);
+  const int first = r * RED_SLICE, n = (a.B - first) < RED_SLICE ? (a.B - first) : RED_SLICE;
+  const float db = block_sum(a.dz_first + (size_t)first * a.ld1, n, a.ld1, sm);
+  float ls = 0.f;
+  if (a.loss_b && a.loss_out) ls = block_sum(a.loss_b + (size_t)first * a.ld1, n, a.ld1, sm);
+  if (R == 1) {
+    if (threadIdx.x == 0) apply_bias_and_loss<LAYOUT, RULE>(a, db, ls);
+    return;
+  }
+  if (threadIdx.x == 0) st_sc1_4(a.red + 4 * r, float4{db, ls, __uint_as_float(a.seq), 0.f});
+  if (INL && r == 0) finish_bias_and_loss<LAYOUT, RULE>(a, R, true);
 }
 
 // The state of one row as LPR lanes hold it: lane q owns coordinates 4q..4q+3; lane 0 also the first-order part.
@@ -589,15 +649,16 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   constexpr int REC = 2 * LPR * 4 + 4;
   constexpr bool PREFETCH_ROWS = EPG <= 4;
   using CA = CoefA<HAS_GBI>;
-  if (blk == 0) {  // the first block (dispatched first) owns the bias and the loss reduction
-    bias_and_loss<LAYOUT, RULE>(a);
+  const int n_red = red_slices(a.B);
+  if (blk < n_red) {  // the first blocks (dispatched first) own the bias and the loss reduction, one slice of the batch each
+    bias_and_loss<LAYOUT, RULE, INL>(a, blk);
     return;
   }
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, q = lane % LPR;
   const int kp = LPR * 4;
   const int tiles_per_field = a.Bp >> 6;
-  const int gt = (blk - 1) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int gt = (blk - n_red) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (gt >= a.F * tiles_per_field) return;
   const int f = gt / tiles_per_field;
   const int base = (gt - f * tiles_per_field) << 6;
@@ -1085,6 +1146,10 @@ __global__ __launch_bounds__(256) void k_fm_fixup(UpdArgs a) {
   const int slot = lane / LPR, q = lane % LPR;
   const int kp = LPR * 4;
   const int tiles_per_field = a.Bp >> 6;
+  if (blockIdx.x == gridDim.x - 1 && red_slices(a.B) > 1) {  // (an extra workgroup: the slices' bias / loss partials, in slice order)
+    finish_bias_and_loss<LAYOUT, RULE>(a, red_slices(a.B), false);
+    return;
+  }
   const int gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (gt >= a.F * tiles_per_field) return;
   const int f = gt / tiles_per_field;
@@ -1734,7 +1799,7 @@ template <int LPR, bool HAS_GBI, bool INL>
 void launch_update(const UpdArgs &a, int rule, hipStream_t st) {
   const int tiles = a.F * (a.Bp >> 6);
   const int wpb = tune().wpb_upd;
-  const dim3 grid((tiles + wpb - 1) / wpb + 1), block(64 * wpb);
+  const dim3 grid((tiles + wpb - 1) / wpb + red_slices(a.B)), block(64 * wpb);
   switch (rule) {
     case FMX_RULE_SIGNADAM:
       hipLaunchKernelGGL((k_fm_update<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, HAS_GBI, INL>), grid, block, 0, st, a);
@@ -1752,7 +1817,7 @@ template <int LPR>
 void launch_fixup(const UpdArgs &a, int rule, hipStream_t st) {
   const int tiles = a.F * (a.Bp >> 6);
   const int wpb = tune().wpb_upd;
-  const dim3 grid((tiles + wpb - 1) / wpb), block(64 * wpb);
+  const dim3 grid((tiles + wpb - 1) / wpb + (red_slices(a.B) > 1 ? 1 : 0)), block(64 * wpb);
   switch (rule) {
     case FMX_RULE_SIGNADAM:
       hipLaunchKernelGGL((k_fm_fixup<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM>), grid, block, 0, st, a);
@@ -1932,6 +1997,7 @@ UpdArgs fill_upd(const fmx_table_t *table, const fmx_hyper_t *hyper, const Works
   a.sorted = sorted;
   a.parts = w.parts;
   a.meta = w.meta;
+  a.red = reinterpret_cast<float *>(w.counter);
   a.xv = xv;
   a.S = S;
   a.dz_first = dz_first;
@@ -2237,6 +2303,89 @@ int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
   const Workspace w = carve(table, B, workspace);
   return update_impl(table, hyper, rule, w, w.sorted, xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out,
                      static_cast<hipStream_t>(stream), nullptr, sample_ld);
+}
+
+// ---- the field-owner step with the library's own communicator (fmx_comm.hip) ----
+static int owner_geometry(const Comm *c, const fmx_table_t *table, int32_t B, int32_t slot, int &GB, const char *who) {
+  if (!c) return fail(FMX_ERR_ARG, "%s: null communicator", who);
+  if (int rc = check_table(table)) return rc;
+  if (B < 1) return fail(FMX_ERR_ARG, "%s: B must be >= 1", who);
+  if (slot < 0 || slot >= FMX_COMM_SLOTS) return fail(FMX_ERR_ARG, "%s: slot %d outside [0, %d)", who, slot, FMX_COMM_SLOTS);
+  if ((int64_t)B * c->world > MAX_SORT_WIDTH) return fail(FMX_ERR_UNSUPPORTED, "%s: %d ranks x %d samples exceed one exact step (%d)", who, c->world, B, MAX_SORT_WIDTH);
+  GB = B * c->world;
+  return check_sort_geometry(table, GB);
+}
+
+int fmx_owner_prefetch(fmx_comm_t *comm, const fmx_table_t *table, const int32_t *idx_local, int32_t B, int32_t slot, int32_t *idx_all,
+                       void *workspace, int64_t workspace_bytes, int32_t *error, fmx_stream_t stream) {
+  Comm *c = reinterpret_cast<Comm *>(comm);
+  int GB = 0;
+  if (int rc = owner_geometry(c, table, B, slot, GB, "fmx_owner_prefetch")) return rc;
+  if (!idx_local || (!idx_all && !(c->world == 1 && !c->force))) return fail(FMX_ERR_ARG, "fmx_owner_prefetch: null argument");
+  if (int rc = check_workspace(table, GB, workspace, workspace_bytes, "fmx_owner_prefetch")) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream), pf = c->pf_stream;
+  // behind whatever wrote idx_local on the caller's stream, and behind the step that last used this slot's buffers
+  (void)hipEventRecord(c->fork, st);
+  (void)hipStreamWaitEvent(pf, c->fork, 0);
+  if (c->used[slot]) (void)hipStreamWaitEvent(pf, c->free_[slot], 0);
+  const size_t words = (size_t)B * n_cols(table);
+  // one rank, nothing forced: no copy -- the lists are sorted from idx_local itself, which the caller then also hands to
+  // fmx_owner_step as idx_all (and keeps unchanged until that step has run)
+  const bool alone = c->world == 1 && !c->force;
+  if (!alone)
+    if (int rc = comm_all_gather(c, 1, idx_local, idx_all, words, pf)) return rc;
+  const Workspace w = carve(table, GB, workspace);
+  if (int rc = sort_impl(table, alone ? idx_local : idx_all, GB, w.sorted, w.runs, error, pf)) return rc;
+  (void)hipEventRecord(c->ready[slot], pf);
+  return FMX_OK;
+}
+
+int fmx_owner_step(fmx_comm_t *comm, const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
+                   const int32_t *idx_all, const float *y_local, int32_t B, int32_t slot, void *workspace, int64_t workspace_bytes,
+                   const fmx_owner_bufs_t *bufs, float *loss_out, int32_t *error, fmx_stream_t stream) {
+  Comm *c = reinterpret_cast<Comm *>(comm);
+  int GB = 0;
+  if (int rc = owner_geometry(c, table, B, slot, GB, "fmx_owner_step")) return rc;
+  if (int rc = check_rule(table, rule)) return rc;
+  if (!hyper || !idx_all || !y_local || !bufs || !bufs->parts_send || !bufs->parts_recv || !bufs->rec_local || !bufs->rec_all)
+    return fail(FMX_ERR_ARG, "fmx_owner_step: null argument");
+  if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "a step needs a loss");
+  if (!aligned16(bufs->parts_send) || !aligned16(bufs->parts_recv) || !aligned16(bufs->rec_local) || !aligned16(bufs->rec_all))
+    return fail(FMX_ERR_ALIGN, "fmx_owner_step: the record buffers must be 16-byte aligned");
+  if (int rc = check_workspace(table, GB, workspace, workspace_bytes, "fmx_owner_step")) return rc;
+  const bool alone = c->world == 1 && !c->force;
+  if (alone ? false : (bufs->parts_recv == bufs->parts_send || bufs->rec_all == bufs->rec_local))
+    return fail(FMX_ERR_ARG, "fmx_owner_step: with an exchange the receive buffers must be buffers of their own");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int kp = table->kp, rec_in = 2 * kp + 4, rec_out = kp + 4;
+  const float inv_b = 1.0f / (float)GB;
+  (void)hipStreamWaitEvent(st, c->ready[slot], 0);  // the slot's gather + sort
+  // 1. every owned block's sub-tree for every sample of the global batch, destination-major
+  if (int rc = part_impl(table, idx_all, nullptr, GB, c->n_blocks, c->block_count[c->rank], B, bufs->parts_send, error, st)) return rc;
+  // 2. the records of this rank's samples from every block
+  if (int rc = comm_exchange_blocks(c, bufs->parts_send, bufs->parts_recv, (size_t)B * rec_in, st)) return rc;
+  // 3. the rest of the tree, bias, loss, dlogit -> one (S, dlogit, loss) record per local sample
+  fmx_fwd_out_t out;
+  memset(&out, 0, sizeof(out));
+  out.S = bufs->rec_local;
+  out.dz = bufs->rec_local + kp;
+  out.loss = bufs->rec_local + kp + 1;
+  out.sample_ld = rec_out;
+  out.error = error;
+  if (int rc = fmx_fm_forward_finish(hyper, table->bias, table->layout, kp, bufs->parts_recv, (int64_t)B * rec_in, c->n_blocks, y_local, B,
+                                     loss_kind, inv_b, &out, stream))
+    return rc;
+  // 4. everybody's records
+  if (int rc = comm_all_gather(c, 0, bufs->rec_local, bufs->rec_all, (size_t)B * rec_out, st)) return rc;
+  // 5. the owned rows (and the replicated bias, identically everywhere)
+  const Workspace w = carve(table, GB, workspace);
+  const float *rec = bufs->rec_all;
+  if (int rc = update_impl(table, hyper, rule, w, w.sorted, nullptr, rec, rec + kp, rec + kp, nullptr, GB, rec + kp + 1, inv_b, loss_out, st,
+                           nullptr, rec_out, error))
+    return rc;
+  (void)hipEventRecord(c->free_[slot], st);
+  c->used[slot] = true;
+  return FMX_OK;
 }
 
 int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,

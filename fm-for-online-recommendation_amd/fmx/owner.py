@@ -24,7 +24,7 @@ same global batch on that table (tests/test_owner_*.py); with one rank the plan 
 
 The compute behind a step is a small backend interface so that the sharding / exchange logic runs on CPU with gloo in the
 tests (an oracle-backed backend injected there; the product has only the HIP one).  fmx_owner_step (include/fmx.h) is the
-same step as ONE C call with the library's own RCCL communicator (HipOwnerBackend.native_step).
+same step as ONE C call with the library's own RCCL communicator: NativeOwnerFM below.
 """
 import ctypes as C
 import os
@@ -124,6 +124,123 @@ class HipOwnerBackend:
 
     def check_error_flag(self):
         self.e.check_error_flag()
+
+
+class NativeOwnerFM:
+    """The field-owner step as ONE C call per step (fmx_owner_prefetch / fmx_owner_step, include/fmx.h) with the library's own
+    RCCL communicator: the kernels of a step, its two exchanges and the events between the step's stream and the prefetch
+    stream are issued from C.  Same interface as FieldOwnerFM (prefetch -> token, step, cancel, check_error_flag), same bits.
+    Needs one GPU per rank (RCCL); torch.distributed is used once, to hand the communicator's ids to the ranks."""
+
+    def __init__(self, backend, group=None, force_collectives=False, stream=None):
+        """stream: the HIP stream (torch stream or int handle) the steps are issued on when a call names none; default: the
+        stream current at construction."""
+        be = self.backend = backend
+        self.lib = be.e.lib
+        self._st = be.e._stream(stream)
+        self._prefetch_fn, self._step_fn = self.lib.fmx_owner_prefetch, self.lib.fmx_owner_step
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert (self.world, self.rank) == (be.world, be.rank)
+        dev = be.device
+        ids = torch.zeros(2 * _lib.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        exchange = self.world > 1 or force_collectives
+        if exchange:
+            if self.rank == 0:
+                buf = (C.c_char * (2 * _lib.COMM_ID_BYTES))()
+                _lib.check(self.lib.fmx_comm_unique_id(buf))
+                ids.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+            if self.world > 1:
+                if dist.get_backend(group) == "gloo":
+                    host = ids.cpu()
+                    dist.broadcast(host, src=0, group=group)
+                    ids.copy_(host)
+                else:
+                    dist.broadcast(ids, src=0, group=group)
+        raw = bytes(ids.cpu().numpy().tobytes())
+        counts = (C.c_int32 * self.world)(*be.block_count)
+        handle = C.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.fmx_comm_create(raw if exchange else None, self.rank, self.world, counts, 1 if force_collectives else 0,
+                                                C.byref(handle)))
+        self.comm = handle
+        self._exchange = exchange
+        self._slots = {}          # slot -> (idx_all, workspace) sized for one global batch
+        self._pref, self._next_slot = {}, 0
+        self._bufs = None
+
+    def __del__(self):
+        comm, self.comm = getattr(self, "comm", None), None
+        if comm:
+            self.lib.fmx_comm_destroy(comm)
+
+    def _slot(self, slot, B):
+        """The slot's buffers for a global batch of world x B samples, and its pre-bound call arguments (a call is then one
+        foreign call plus a pointer or two: the structs, buffers and sizes of a slot only change when the engine grows)."""
+        be, GB = self.backend, B * self.world
+        be.e._ensure(GB)
+        key = (GB, be.table._sort_split[1].numel() if be.table._sort_split is not None else 0)
+        cur = self._slots.get(slot)
+        if cur is None or cur[0] != key:
+            idx_all = torch.empty((GB, be.table.n_cols), dtype=torch.int32, device=be.device) if self._exchange else None
+            ws = be.e.new_workspace(GB)
+            torch.cuda.current_stream(be.device).synchronize()      # (a new zero-filled workspace: rare, and ordered before the prefetch stream uses it)
+            bufs = self._step_bufs(B)
+            t, e = be.table.c_struct(), be.e
+            pre = (_ptr(idx_all), ws.data_ptr(), ws.numel() * 4, e.error.data_ptr())
+            post = (B, slot, ws.data_ptr(), ws.numel() * 4, C.byref(bufs), e.loss_out.data_ptr(), e.error.data_ptr())
+            head = (self.comm, t, be.hyper.ref(), _lib.RULES[be.rule], _lib.LOSSES[be.loss])
+            cur = self._slots[slot] = (key, idx_all, ws, pre, post, head, t)
+        return cur
+
+    def _step_bufs(self, B):
+        be = self.backend
+        if self._bufs is None or self._bufs[0] != B:
+            f32 = dict(dtype=torch.float32, device=be.device)
+            send = torch.zeros((self.world * be.nlb * B, be.rec_in), **f32)
+            rec = torch.zeros((B, be.rec_out), **f32)
+            recv = torch.zeros((be.nb * B, be.rec_in), **f32) if self._exchange else send
+            rec_all = torch.zeros((self.world * B, be.rec_out), **f32) if self._exchange else rec
+            c = _lib.OwnerBufs(send.data_ptr(), recv.data_ptr(), rec.data_ptr(), rec_all.data_ptr())
+            self._bufs = (B, c, (send, recv, rec, rec_all))
+        return self._bufs[1]
+
+    def prefetch(self, idx_next, stream=None):
+        """The weights-free part of a LATER step, now, on the communicator's own stream (behind `stream` as it is at this call):
+        all-gather of the ranks' idx_next [B, F], occurrence sort of the owned pieces.  -> token for step(), None when every
+        slot is taken.  With one rank nothing is copied: idx_next must stay unchanged until its step has run."""
+        if len(self._pref) >= _lib.COMM_SLOTS:
+            return None
+        be, B = self.backend, idx_next.shape[0]
+        busy = {s for _, s, _, _ in self._pref.values()}
+        slot = self._next_slot
+        while slot in busy:
+            slot = (slot + 1) % _lib.COMM_SLOTS
+        self._next_slot = (slot + 1) % _lib.COMM_SLOTS
+        cur = self._slot(slot, B)
+        _lib.check(self._prefetch_fn(self.comm, cur[6], idx_next.data_ptr(), B, slot, *cur[3], self._st if stream is None else be.e._stream(stream)))
+        token = object()
+        self._pref[id(token)] = (token, slot, B, idx_next)
+        return token
+
+    def cancel(self, token):
+        self._pref.pop(id(token), None)
+
+    def check_error_flag(self):
+        self.backend.check_error_flag()
+
+    def step(self, idx_local, y_local, token=None, stream=None):
+        be, B = self.backend, idx_local.shape[0]
+        pref = self._pref.pop(id(token), None) if token is not None else None
+        if pref is None:                             # nothing prepared: the gather and the sort now, then the step
+            token = self.prefetch(idx_local, stream=stream)
+            pref = self._pref.pop(id(token))
+        _, slot, Bp, idx_src = pref
+        assert Bp == B
+        cur = self._slot(slot, B)
+        idx_all = cur[1].data_ptr() if self._exchange else idx_src.data_ptr()
+        _lib.check(self._step_fn(*cur[5], idx_all, y_local.data_ptr(), *cur[4], self._st if stream is None else be.e._stream(stream)))
+        return be.e.loss_out
 
 
 def _max_step_batch(max_field_rows):

@@ -210,6 +210,39 @@ int fmx_fm_forward_finish(const fmx_hyper_t *hyper, const float *bias, int32_t l
                           int64_t owner_stride, int32_t n_owners, const float *y, int32_t B, int32_t loss_kind, float inv_b,
                           const fmx_fwd_out_t *out, fmx_stream_t stream);
 
+/* ---- the field-owner step as ONE call per step, with the library's own RCCL communicator (one process per GPU) ----
+ * What fmx/owner.py's FieldOwnerFM does with torch.distributed collectives between three ctypes calls -- 70 us of host time per
+ * step -- as two entry points: fmx_owner_prefetch (weights-free, ahead of time, on the communicator's own stream: all-gather of
+ * the ranks' index batches, occurrence sort of the owned pieces over the global batch) and fmx_owner_step (partial forward ->
+ * all-to-all of the per-block records -> finish -> all-gather of (S, dlogit, loss) -> update of the owned rows), every launch
+ * and both exchanges issued from C on `stream`.  RCCL is loaded at run time (librccl.so.1); with one rank nothing is exchanged
+ * (flags bit 0 forces the calls: the RCCL path on a one-GPU box) and RCCL is not needed.
+ *   fmx_comm_unique_id   rank 0 fills 2 x FMX_COMM_ID_BYTES bytes (two ncclUniqueId: the step's communicator and the prefetch
+ *                        stream's -- operations of ONE RCCL communicator are serialised in issue order whatever their stream);
+ *                        the host side broadcasts them (torch.distributed) and every rank calls fmx_comm_create
+ *   block_count [world]  tree blocks per rank (fmx.plan.OwnerPlan.block_count; null: one each)
+ * A slot (0 .. FMX_COMM_SLOTS-1) names one batch in flight: fmx_owner_prefetch(slot) orders itself behind `stream` as it is at
+ * the call and behind the last fmx_owner_step that used the slot; fmx_owner_step(slot) waits for that prefetch.  The caller owns
+ * every buffer: idx_all [world B, n_cols] and the workspace of the slot, parts_send [world][blocks of this rank][B, 2 kp + 4],
+ * parts_recv [n_blocks][B, 2 kp + 4], rec_local [B, kp + 4], rec_all [world B, kp + 4] (with one rank and no forced collectives
+ * parts_recv may be parts_send and rec_all rec_local, and nothing is copied: fmx_owner_prefetch sorts from idx_local, idx_all may be
+ * null there, and the caller hands the same idx_local to fmx_owner_step as idx_all).  Same results, bit for bit, as the separate calls.
+ * Replaces: reference fm_adam.py:56-69 (update_embedding: forward_fm, loss, backward, optimizer) on a batch sharded over ranks. */
+#define FMX_COMM_ID_BYTES 128
+#define FMX_COMM_MAX_WORLD 16
+typedef struct fmx_comm fmx_comm_t;
+typedef struct fmx_owner_bufs {
+  float *parts_send, *parts_recv, *rec_local, *rec_all;
+} fmx_owner_bufs_t;
+int fmx_comm_unique_id(void *ids_out);
+int fmx_comm_create(const void *ids, int32_t rank, int32_t world, const int32_t *block_count, int32_t flags, fmx_comm_t **out);
+int fmx_comm_destroy(fmx_comm_t *comm);
+int fmx_owner_prefetch(fmx_comm_t *comm, const fmx_table_t *table, const int32_t *idx_local, int32_t B, int32_t slot, int32_t *idx_all,
+                       void *workspace, int64_t workspace_bytes, int32_t *error, fmx_stream_t stream);
+int fmx_owner_step(fmx_comm_t *comm, const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, int32_t loss_kind,
+                   const int32_t *idx_all, const float *y_local, int32_t B, int32_t slot, void *workspace, int64_t workspace_bytes,
+                   const fmx_owner_bufs_t *bufs, float *loss_out, int32_t *error, fmx_stream_t stream);
+
 /* Occurrence lists: for every field, the batch's (local index, sample) pairs sorted by index then sample.
  * Replaces: the duplicate-row summation embedding_dense_backward performs inside loss.backward()
  * (reference fm_adam.py:67,81) -- sorting is what makes "reduce per unique row, then

@@ -416,3 +416,71 @@ def test_rccl_collectives_of_a_step_with_one_rank():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "field owners, nccl, 1 rank, forced collectives: 20 steps bit-identical" in r.stdout
     assert "replicated mode, nccl, 1 rank, forced collectives: bit-identical" in r.stdout
+    assert "fmx_owner_step, own RCCL communicator, 1 rank, forced collectives: 20 steps bit-identical" in r.stdout
+
+
+def test_native_owner_step_single_rank_equals_plain_steps():
+    """fmx_owner_prefetch / fmx_owner_step (one C call per step; with one rank nothing is exchanged and RCCL is not loaded)
+    against fmx_fm_step on the same batches: the same bits, with and without prepared slots."""
+    import fmx
+    from fmx.owner import HipOwnerBackend, NativeOwnerFM
+    from fmx.plan import OwnerPlan
+    sizes, k, B, steps = CRITEO_SIZES, 16, 2048, 6
+    batches = _batches(sizes, B, steps)
+    t_ref, ref_losses = _whole_run(fmx, OwnerPlan(sizes, k, 1), sizes, k, "ftrl", batches)
+    be = HipOwnerBackend(sizes, k, fmx.Hyper(**HYP), "ftrl", "logits", 0, 1, ftrl=HYP, max_local_batch=B)
+    _load(be.table, sizes, *_weights(sizes, k))
+    data = [(torch.from_numpy(i).cuda(), torch.from_numpy(y).cuda()) for i, y in batches]
+    work = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    nat = NativeOwnerFM(be, stream=work)                                                    # the stream its calls go to
+    losses = []
+    with torch.cuda.stream(work):
+        tokens = {0: nat.prefetch(data[0][0]), 1: nat.prefetch(data[1][0])}
+        for i, (idx_d, y_d) in enumerate(data):
+            losses.append(nat.step(idx_d, y_d, tokens.pop(i, None)).clone())
+            if i + 2 < steps and i != 1:                                                    # step 3 runs with nothing prepared
+                tokens[i + 2] = nat.prefetch(data[i + 2][0])
+    torch.cuda.synchronize()
+    nat.check_error_flag()
+    assert [float(l[0]) for l in losses] == ref_losses
+    np.testing.assert_array_equal(be.table.rows.cpu().numpy(), t_ref.rows.cpu().numpy())
+    np.testing.assert_array_equal(be.table.bias.cpu().numpy(), t_ref.bias.cpu().numpy())
+
+
+def test_owner_entry_points_reject_bad_arguments():
+    import ctypes as C
+    import fmx
+    from fmx.owner import HipOwnerBackend, NativeOwnerFM
+    lib = fmx._lib.load()
+    be = HipOwnerBackend([50, 7, 300], 16, fmx.Hyper(**HYP), "sgd", "logits", 0, 1, max_local_batch=256)
+    nat = NativeOwnerFM(be)
+    idx = torch.zeros((256, 3), dtype=torch.int32, device="cuda")
+    y = torch.zeros(256, device="cuda")
+    ws = nat._slot(0, 256)[2]
+    idx_all = torch.zeros((256, 3), dtype=torch.int32, device="cuda")
+    bufs = nat._step_bufs(256)
+    err, st = be.e.error.data_ptr(), 0
+    t, h = be.table.c_struct(), be.hyper.ref()
+    E = fmx._lib
+    assert lib.fmx_owner_prefetch(None, t, idx.data_ptr(), 256, 0, idx_all.data_ptr(), ws.data_ptr(), ws.numel() * 4, err, st) == E.ERR_ARG
+    assert lib.fmx_owner_prefetch(nat.comm, t, idx.data_ptr(), 256, 9, idx_all.data_ptr(), ws.data_ptr(), ws.numel() * 4, err, st) == E.ERR_ARG
+    assert lib.fmx_owner_prefetch(nat.comm, t, None, 256, 0, idx_all.data_ptr(), ws.data_ptr(), ws.numel() * 4, err, st) == E.ERR_ARG
+    assert lib.fmx_owner_prefetch(nat.comm, t, idx.data_ptr(), 256, 0, idx_all.data_ptr(), ws.data_ptr(), 64, err, st) == E.ERR_SHAPE
+    assert lib.fmx_owner_prefetch(nat.comm, t, idx.data_ptr(), 40000, 0, idx_all.data_ptr(), ws.data_ptr(), ws.numel() * 4, err, st) == E.ERR_UNSUPPORTED
+    assert b"exceed one exact step" in lib.fmx_last_error_string()
+    step = lambda *a: lib.fmx_owner_step(*a)
+    assert step(nat.comm, t, h, E.RULE_SGD, E.LOSS_BCE_LOGITS, idx_all.data_ptr(), y.data_ptr(), 256, 0, ws.data_ptr(), ws.numel() * 4, None,
+                be.e.loss_out.data_ptr(), err, st) == E.ERR_ARG
+    assert step(nat.comm, t, h, E.RULE_FTRL, E.LOSS_BCE_LOGITS, idx_all.data_ptr(), y.data_ptr(), 256, 0, ws.data_ptr(), ws.numel() * 4,
+                C.byref(bufs), be.e.loss_out.data_ptr(), err, st) == E.ERR_ARG                 # the rule does not fit the table's layout
+    assert step(nat.comm, t, h, E.RULE_SGD, E.LOSS_NONE, idx_all.data_ptr(), y.data_ptr(), 256, 0, ws.data_ptr(), ws.numel() * 4,
+                C.byref(bufs), be.e.loss_out.data_ptr(), err, st) == E.ERR_ARG
+    bad = fmx._lib.OwnerBufs(bufs.parts_send + 4, bufs.parts_recv, bufs.rec_local, bufs.rec_all)
+    assert step(nat.comm, t, h, E.RULE_SGD, E.LOSS_BCE_LOGITS, idx_all.data_ptr(), y.data_ptr(), 256, 0, ws.data_ptr(), ws.numel() * 4,
+                C.byref(bad), be.e.loss_out.data_ptr(), err, st) == E.ERR_ALIGN
+    ids = (C.c_char * 256)()
+    out = C.c_void_p()
+    assert lib.fmx_comm_create(ids, 3, 2, None, 0, C.byref(out)) == E.ERR_ARG                   # rank outside the world
+    assert lib.fmx_comm_create(None, 0, 2, None, 0, C.byref(out)) == E.ERR_ARG                  # two ranks need the ids
+    assert lib.fmx_comm_create(None, 0, 1, None, 0, None) == E.ERR_ARG

@@ -54,6 +54,27 @@ assert torch.equal(obe.table.rows, ref.rows), "field owners over RCCL (one rank)
 assert torch.equal(lo, loss_ref), "losses differ"
 print("field owners, nccl, 1 rank, forced collectives: %d steps bit-identical to fmx_fm_stream; last loss %.6f" % (STEPS, float(lo[-1])), flush=True)
 
+# the same through the one-call-per-step entry points with the library's own RCCL communicator, collectives forced
+from fmx.owner import NativeOwnerFM
+obe2 = HipOwnerBackend(sizes, K, hyper, "ftrl", "logits", 0, 1, ftrl=B.HYPER, device=dev, max_local_batch=BATCH)
+init(obe2.table)
+nat = NativeOwnerFM(obe2, force_collectives=True, stream=work)
+losses = []
+with torch.cuda.stream(work):
+    tokens = {d: nat.prefetch(idx_pool[d % NP]) for d in range(2)}
+    for s in range(STEPS):
+        out = nat.step(idx_pool[s % NP], y_pool[s % NP], tokens.pop(s, None))
+        losses.append(out.clone())
+        if s + 2 < STEPS:
+            tokens[s + 2] = nat.prefetch(idx_pool[(s + 2) % NP])
+torch.cuda.synchronize()
+obe2.e.check_error_flag()
+lo = torch.cat([l.reshape(-1)[:1] for l in losses])
+assert torch.equal(obe2.table.rows, ref.rows), "fmx_owner_step over RCCL (one rank): rows differ from the one-GPU loop"
+assert torch.equal(lo, loss_ref), "fmx_owner_step: losses differ"
+print("fmx_owner_step, own RCCL communicator, 1 rank, forced collectives: %d steps bit-identical to fmx_fm_stream" % STEPS, flush=True)
+del nat
+
 # replicated mode
 t2 = fmx.FlatTable(sizes, K, layout="ftrl", device=dev, ftrl=B.HYPER)
 init(t2)

@@ -66,3 +66,24 @@ with torch.cuda.stream(work):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 print(f"FieldOwnerFM.step at G = 1 (no collectives), host included: {dt / 300 * 1e6:.1f} us/step = {300 * B / dt / 1e6:.1f} M samples/s")
+
+# the same loop through fmx_owner_prefetch / fmx_owner_step (one C call each per step), and what the HOST spends per step
+from fmx.owner import NativeOwnerFM
+nat = NativeOwnerFM(be, stream=work)
+idx_l, y_l = [idx_pool[j] for j in range(8)], [y_pool[j] for j in range(8)]
+def run_native(n):
+    tokens = {0: nat.prefetch(idx_l[0]), 1: nat.prefetch(idx_l[1])}
+    for s in range(n):
+        nat.step(idx_l[s % 8], y_l[s % 8], tokens.pop(s, None))
+        if s + 2 < n:
+            tokens[s + 2] = nat.prefetch(idx_l[(s + 2) % 8])
+with torch.cuda.stream(work):
+    run_native(20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_native(300)
+    t_host = time.perf_counter() - t0          # the host is done issuing; the device still runs
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print(f"NativeOwnerFM.step at G = 1 (fmx_owner_step, no collectives): {dt / 300 * 1e6:.1f} us/step = {300 * B / dt / 1e6:.1f} M samples/s; "
+      f"host time issuing a step (prefetch + step calls) {t_host / 300 * 1e6:.1f} us")
