@@ -115,15 +115,24 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
     FMX_MLP_NATIVE=0 runs it through PyTorch autograd instead (rocBLAS; FMX_MLP_GRAPH=1 replays it as a graph)."""
     import torch.nn as nn
     lr, hidden, n_layers = 1e-3, 256, 3
-    table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="weights", device=dev)
-    g = torch.Generator(device=dev).manual_seed(SEED)
-    table.rows[:, :K_EMB] = torch.randn((table.n_rows, K_EMB), generator=g, device=dev) * 0.01
     torch.manual_seed(SEED)                                   # identical MLP replicas on every rank
     layers = [nn.Linear(K_EMB if j == 0 else hidden, hidden).to(dev) for j in range(n_layers)]
-    eng = fmx.FMEngine(table, max_batch=BATCH * world)
-    tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=lr), "sgd"), layers, K_EMB, table.kp, mlp_lr=lr,
-                           use_graph=os.environ.get("FMX_MLP_GRAPH", "1") == "1",
-                           native_mlp=os.environ.get("FMX_MLP_NATIVE", "1") == "1")
+    owners = world > 1 and args.mp_mode == "owner"
+    if owners:
+        # N > 1: the scalable mode -- tables and update work sharded over field owners, the MLP replicated; per step one
+        # all-to-all + one record all-gather on the critical path, ONE all-reduce of the MLP gradients beside the table update
+        from fmx.owner import HipOwnerBackend
+        obe = HipOwnerBackend(CRITEO_SIZES, K_EMB, fmx.Hyper(lr=lr), "sgd", "logits", rank, world, device=dev, max_local_batch=BATCH)
+        table, eng = obe.table, obe.e
+        tr = fmx.OwnerDeepFMTrainer(obe, layers, K_EMB, mlp_lr=lr)
+    else:
+        table = fmx.FlatTable(CRITEO_SIZES, K_EMB, layout="weights", device=dev)
+        eng = fmx.FMEngine(table, max_batch=BATCH * world)
+        tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=lr), "sgd"), layers, K_EMB, table.kp, mlp_lr=lr,
+                               use_graph=os.environ.get("FMX_MLP_GRAPH", "1") == "1",
+                               native_mlp=os.environ.get("FMX_MLP_NATIVE", "1") == "1")
+    g = torch.Generator(device=dev).manual_seed(SEED + rank)
+    table.rows[:, :K_EMB] = torch.randn((table.n_rows, K_EMB), generator=g, device=dev) * 0.01
     idx_np, y_np = synth_pool(N_POOL, BATCH, CRITEO_SIZES, SEED + 1000 * rank, zipf=args.zipf)
     idx_pool, y_pool = torch.from_numpy(idx_np).to(dev), torch.from_numpy(y_np).to(dev)
 
@@ -135,6 +144,15 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
 
     def run(n, first=0):
         out = None
+        if owners:                                            # the index all-gather and the sort of the owned pieces run two steps ahead
+            tokens = {d: tr.prefetch(idx_pool[(first + d) % N_POOL]) for d in range(min(2, n))}
+            for s in range(n):
+                j = (first + s) % N_POOL
+                out = tr.step(idx_pool[j], y_pool[j], tokens.pop(s, None))
+                if s + 2 < n:
+                    tokens[s + 2] = tr.prefetch(idx_pool[(first + s + 2) % N_POOL])
+            tr.finish()
+            return out
         for s in range(n):
             out = tr.step(idx_pool[(first + s) % N_POOL], y_pool[(first + s) % N_POOL])
         return out
@@ -164,12 +182,15 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
         "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "online DeepFM fwd+bwd, fused SGD row update of the tables, "
-                               + ("fp32-MFMA" if tr.native else "PyTorch") + " MLP 16-256-256-256 "
+                               + ("fp32-MFMA" if getattr(tr, "native", True) else "PyTorch") + " MLP 16-256-256-256 "
                                f"({mlp_params} parameters, {mlp_params * 4} B all-reduced per step when N > 1), synthetic "
                                f"Criteo-39 (R=1,006,628, k=16, B={BATCH} per GPU); BASELINE.json configs[3]",
                    "global_batch": BATCH * world,
-                   "parallelism": "1 GPU" if world == 1 else f"dp{world}: all-gather of (idx, S, dz, dL/dbi) + one all-reduce "
-                                                             "of the MLP gradients (exact)"},
+                   "parallelism": "1 GPU" if world == 1 else
+                   (f"field owners x{world}: tables and update work sharded, MLP replicated; per step an all-to-all of partial sums and ONE "
+                    "all-gather of (S, dlogit, dL/dbi) records on the critical path, ONE all-reduce of the MLP gradients beside the table "
+                    "update, the index all-gather ahead of time (exact)" if owners else
+                    f"dp{world}: all-gather of (idx, S, dz, dL/dbi) + one all-reduce of the MLP gradients (exact, replicated tables)")},
         "mlp_section": {"flop_per_step": flops, "note": "3 x (forward + dgrad + wgrad) fp32-MFMA GEMMs; TFLOP/s over the WHOLE step "
                         "(tables included) is a lower bound of the section's rate", "TFLOPs_whole_step": flops / (dt / steps) / 1e12,
                         "frac_of_fp32_mfma_peak_whole_step": flops / (dt / steps) / 1e12 / 157.3},

@@ -455,6 +455,7 @@ struct UpdArgs {
   fmx_hyper_t h;
   int32_t B, F, Bp, bbits, kp, stride, zoff;
   int32_t ldS, ld1;  // floats between consecutive samples in S and in dz_first / dz_bi / loss_b (kp and 1 when dense)
+  int32_t ldG;       // ... and in gbi (kp when dense)
   const int32_t *cols;  // sort field -> field, or null; fcols: field -> column of xv, or null; Fx: columns of xv
   const int32_t *fcols;
   int32_t Fx;
@@ -743,7 +744,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
       xl[j] = xsrc[has_x ? (size_t)b * a.Fx + col : (size_t)0];
       dzf[j] = a.dz_first[(size_t)b * a.ld1];
       dzbl[j] = bisrc[(size_t)b * a.ld1];
-      if constexpr (HAS_GBI) G4[j] = *reinterpret_cast<const float4 *>(a.gbi + (size_t)b * kp + 4 * q);
+      if constexpr (HAS_GBI) G4[j] = *reinterpret_cast<const float4 *>(a.gbi + (size_t)b * a.ldG + 4 * q);
       else G4[j] = splat(0.f);
     }
     if (!tile_open_early) request_rows();
@@ -1984,6 +1985,7 @@ UpdArgs fill_upd(const fmx_table_t *table, const fmx_hyper_t *hyper, const Works
   UpdArgs a;
   a.ldS = sample_ld > 0 ? sample_ld : table->kp;
   a.ld1 = sample_ld > 0 ? sample_ld : 1;
+  a.ldG = sample_ld > 0 ? sample_ld : table->kp;
   static std::atomic<uint32_t> launch_seq{1};
   a.seq = launch_seq.fetch_add(1) & 0x0FFFFFFFu;
   if (a.seq == 0) a.seq = launch_seq.fetch_add(1) & 0x0FFFFFFFu;  // 0 is what a zeroed workspace holds

@@ -8,4 +8,4 @@ from . import _lib  # noqa: F401
 from .table import FlatTable, padded_k  # noqa: F401
 from .engine import FMEngine, Hyper, normalize_inputs  # noqa: F401
 from .distributed import DataParallelFM, HipBackend  # noqa: F401
-from .deep import DeepFMTrainer, HipDeepBackend  # noqa: F401
+from .deep import DeepFMTrainer, HipDeepBackend, OwnerDeepFMTrainer  # noqa: F401

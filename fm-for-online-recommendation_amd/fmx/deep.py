@@ -187,3 +187,101 @@ class DeepFMTrainer:
                 p -= self.mlp_lr * flat[off:off + n].view_as(p)
                 off += n
         return loss
+
+
+class OwnerDeepFMTrainer:
+    """Online DeepFM / NFM on FIELD OWNERS (fmx.owner, fmx.plan): the tables and their update work shard over the ranks, the MLP is
+    replicated.  Per step and rank (B local samples, G ranks; BASELINE.json configs[3]):
+
+        (ahead of time)  all-gather idx, sort the owned pieces' occurrences                       prefetch(): 1 collective, off the critical path
+        partial forward  the owned blocks' sub-trees for every sample of the global batch
+        all-to-all       the records of this rank's samples                                         collective 1 of the critical path
+        finish           S, bi, first-order sum, FM logit of the B local samples
+        MLP section      forward, loss, backward on bi (fmx_mlp_section, fp32 MFMA) -> dlogit, dL/dbi, local MLP gradients
+        all-reduce       the flattened MLP gradients (3 x 256: 544 KB), ONE bucket, on a side stream:   beside the table update
+                         it does not touch the tables -- then SGD on the replicated MLP
+        all-gather       ONE record per sample: S | dlogit | dL/dbi (144 B at k = 16)               collective 2 of the critical path
+        update           the owned rows (every row by its owner only)
+
+    The dense exchange is what north_star names (reference deepfm_adam.py:38-44,82-88: nn.Linear layers, replicated); no embedding
+    row crosses xGMI.  The tables end bit-identical on every rank to the one-table step while the MLP parameters agree (they differ
+    by the all-reduce's summation order from the second step on: 1e-5, tests/test_dp_gpu.py)."""
+
+    def __init__(self, backend, hidden_layers, k, mlp_lr, fm_term=True, loss="logits", group=None):
+        be = self.backend = backend
+        self.layers, self.k, self.kp = list(hidden_layers), k, be.kp
+        self.mlp_lr, self.fm_term, self.loss, self.group = mlp_lr, fm_term, loss, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._gloo = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        self.params = [p for layer in self.layers for p in (layer.weight, layer.bias)]
+        widths = {layer.out_features for layer in self.layers} | {layer.in_features for layer in self.layers[1:]}
+        if not (len(widths) == 1 and self.layers[0].in_features == k and len(self.layers) <= 8):
+            raise ValueError("OwnerDeepFMTrainer runs the MLP through fmx_mlp_section: equal hidden widths, at most 8 layers")
+        self.hidden = self.layers[0].out_features
+        self.flat = torch.cat([p.detach().reshape(-1) for p in self.params]).contiguous()
+        self.gflat = torch.zeros_like(self.flat)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.data = self.flat[off:off + n].view_as(p)
+            off += n
+        from .owner import FieldOwnerFM
+        self.fo = FieldOwnerFM(be, group)            # its exchanges (all-gather, all-to-all) and its prefetch slots
+        self._side, self._ar_done = None, None
+
+    def prefetch(self, idx_next):
+        return self.fo.prefetch(idx_next)
+
+    def step(self, idx_local, y_local, token=None):
+        """One exact step on the global batch; returns this rank's share of the global mean loss (sum over ranks = the loss)."""
+        be, fo, B = self.backend, self.fo, idx_local.shape[0]
+        dev = idx_local.device
+        inv_b = 1.0 / (B * self.world)
+        gpu = idx_local.is_cuda                       # (the tests drive the exchange logic on CPU with an oracle-backed backend)
+        cur = torch.cuda.current_stream(dev) if gpu else None
+        kw = {"stream": cur} if gpu else {}
+        pref = fo._pref.pop(id(token), None) if token is not None else None
+        if pref is not None:
+            _, idx_all, slot = pref
+            cur.wait_event(fo._pf[1][slot])
+        else:
+            idx_all, slot = fo._all_gather("idx", idx_local), None
+        parts = be.partial_forward(idx_all, B, **kw)
+        mine = fo._all_to_all("parts", parts, B)
+        rec, bi, sfirst, logit_fm = be.finish_bi(mine, **kw)
+        base_in = logit_fm if self.fm_term else sfirst + be.bias_weight()
+        if self._ar_done is not None:                 # the previous step's SGD on the MLP (side stream) comes first
+            cur.wait_event(self._ar_done)
+        alone = self.world == 1
+        loss, dz, gbi = be.mlp_section(self.flat, self.gflat, self.k, self.hidden, len(self.layers), self.loss, bi,
+                                       base_in.contiguous(), y_local, B, inv_b, self.mlp_lr if alone else 0.0)
+        if not alone and gpu:                         # the dense exchange: one bucket, beside the table update
+            if self._side is None:
+                self._side, self._ar_done = torch.cuda.Stream(device=dev), torch.cuda.Event()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                if self._gloo:
+                    host = self.gflat.cpu()
+                    dist.all_reduce(host, group=self.group)
+                    self.gflat.copy_(host)
+                else:
+                    dist.all_reduce(self.gflat, group=self.group)
+                self.flat.sub_(self.gflat, alpha=self.mlp_lr)
+            self._ar_done.record(self._side)
+        elif not alone:
+            dist.all_reduce(self.gflat, group=self.group)
+            self.flat.sub_(self.gflat, alpha=self.mlp_lr)
+        kp = self.kp
+        rec[:, kp] = dz                               # the record: S (written by the finish) | dlogit | dL/dbi
+        rec[:, kp + 4:] = gbi
+        rec_all = fo._all_gather("deep_rec", rec)
+        be.update_deep(idx_all, rec_all, self.fm_term, inv_b, slot, **kw) if slot is not None else be.update_deep(idx_all, rec_all, self.fm_term, inv_b, **kw)
+        if slot is not None:
+            fo._pf[2][slot].record(cur)
+        return loss[0]
+
+    def finish(self):
+        """Order the caller's stream behind the last step's MLP update (call before reading the MLP parameters)."""
+        if self._ar_done is not None:
+            torch.cuda.current_stream(self.backend.device).wait_event(self._ar_done)

@@ -122,6 +122,53 @@ class HipOwnerBackend:
         self.e.update(self.hyper, self.rule, GB, None, None, inv_b=inv_b, with_loss=True, records=rec_g, workspace=ws, stream=stream)
         return self.e.loss_out
 
+    # ---- DeepFM / NFM on field owners (fmx.deep.OwnerDeepFMTrainer): the finish without a loss, records carrying dL/dbi ----
+    def deep_record_ld(self):
+        """floats per sample of the record the ranks all-gather: S [kp] | dlogit, 0, 0, 0 | dL/dbi [kp]."""
+        return 2 * self.kp + 4
+
+    def finish_bi(self, parts_mine, stream=None):
+        """parts_mine [NB, B, 2 kp + 4] -> (rec [B, 2 kp + 4] with S in its first kp floats, bi [B, kp], sfirst [B], logit [B]) of
+        the local samples; no loss here: it comes out of the MLP section."""
+        NB, B = parts_mine.shape[0], parts_mine.shape[1]
+        ld = self.deep_record_ld()
+        rec = self._buf("deep_rec", (B, ld))
+        bi, sfirst, logit = self._buf("deep_bi", (B, self.kp)), self._buf("deep_sfirst", (B,)), self._buf("deep_logit", (B,))
+        out = self._bufs.get(("deep_out", B))
+        if out is None:
+            out = self._bufs[("deep_out", B)] = _lib.FwdOut()
+            out.S, out.sample_ld = rec.data_ptr(), ld
+            out.bi, out.sfirst, out.logit, out.error = bi.data_ptr(), sfirst.data_ptr(), logit.data_ptr(), self.e.error.data_ptr()
+        t = self.table
+        _lib.check(self.e.lib.fmx_fm_forward_finish(self.hyper.ref(), t.bias.data_ptr(),
+                                                   _lib.LAYOUT_WEIGHTS if t.layout == "weights" else _lib.LAYOUT_FTRL, t.kp,
+                                                   parts_mine.data_ptr(), B * self.rec_in, NB, None, B, _lib.LOSS_NONE, 1.0,
+                                                   C.byref(out), self.e._stream(stream)))
+        return rec, bi, sfirst, logit
+
+    def update_deep(self, idx_all, rec_all, fm_term, inv_b, slot=None, stream=None):
+        """The owned rows from the gathered records [G B, 2 kp + 4] = (S | dlogit, - | dL/dbi): G = (fm_term ? dlogit : 0) + dL/dbi."""
+        GB, kp, ld = idx_all.shape[0], self.kp, rec_all.shape[1]
+        self.e._ensure(GB)
+        if slot is None:
+            self.e.sort(idx_all, stream=stream)
+            ws = self.e.workspace
+        else:
+            ws, fresh = self._slot_ws(slot, GB)
+            assert not fresh
+        base = rec_all.data_ptr()
+        dz = base + 4 * kp
+        _lib.check(self.e.lib.fmx_fm_update(self.table.c_struct(), self.hyper.ref(), _lib.RULES[self.rule], ws.data_ptr(),
+                                           ws.numel() * ws.element_size(), None, base, dz, dz if fm_term else None, base + 4 * (kp + 4),
+                                           GB, ld, None, inv_b, None, self.e._stream(stream)))
+
+    def bias_weight(self):
+        return self.table.bias_weight()
+
+    def mlp_section(self, flat, gflat, k, hidden, n_layers, loss, bi, base, y, B, inv_b, lr_apply):
+        """The replicated MLP on the local samples' bi (fmx_mlp_section: fp32 MFMA) -> (loss [1], dlogit [B], dL/dbi [B, kp])."""
+        return self.e.mlp_section(flat, gflat, k, hidden, n_layers, loss, bi, base, y, B, inv_b, lr_apply)
+
     def check_error_flag(self):
         self.e.check_error_flag()
 

@@ -170,6 +170,30 @@ class OwnerPlan:
                 f"rows per owner {rows} (max/min {max(rows) / max(1, min(rows)):.2f})")
 
 
+class WholeOwnerPlan:
+    """The same pieces at the same positions held by ONE rank that owns every block: the plan a single process runs the owner
+    step with when it must give the bits of `plan.world` ranks (tests; a one-GPU replay of a multi-GPU run)."""
+
+    def __init__(self, plan):
+        self.inner, self.world, self.sizes, self.k, self.kp = plan, 1, plan.sizes, plan.k, plan.kp
+        self.nb, self.sl, self.np, self.slots = plan.nb, plan.sl, plan.np, plan.slots
+        self.block_count, self.block_first = [plan.nb], [0]
+
+    def owner_fields(self, g):
+        return sum((self.inner._fields_of_block(b) for b in range(self.nb)), [])
+
+    def table_for_owner(self, g, layout="weights", device=None, ftrl=None):
+        fields = self.owner_fields(0)
+        if self.inner.world == 1:
+            t = FlatTable(self.sizes, self.k, layout=layout, device=device, ftrl=ftrl)
+            t.plan_fields = [(c, 0, r) for c, r in enumerate(self.sizes)]
+            return t
+        t = FlatTable([r for _, _, r in fields], self.k, layout=layout, device=device, ftrl=ftrl,
+                      field_cols=[c for c, _, _ in fields], field_base=[b for _, b, _ in fields], n_cols=len(self.sizes))
+        t.plan_fields = fields
+        return t
+
+
 def load_columns(table, first_list, second_list):
     """Fill a plan table from per-COLUMN reference weights (first_list[c] [rows_c, 1], second_list[c] [rows_c, k]): every field
     takes its row range of its column (FlatTable.load_reference wants one tensor per field)."""

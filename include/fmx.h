@@ -267,7 +267,8 @@ int fmx_sort_occurrences(const fmx_table_t *table, const int32_t *idx, int32_t B
  *   dz_bi     [B] or null: scalar coefficient on every bi component (the FM term sum_d bi_d)
  *   gbi       [B, kp] or null: dL/dbi from a network on top of bi (DeepFM / NFM)
  *   loss_b    [B] or null with loss_out [1] or null: loss_out = inv_b * sum_b loss_b (deterministic order)
- *   sample_ld 0, or the record stride of fmx_fwd_out_t.sample_ld: applies to S, dz_first, dz_bi and loss_b (gbi is dense)
+ *   sample_ld 0, or the record stride of fmx_fwd_out_t.sample_ld: applies to S, dz_first, dz_bi, loss_b and gbi (fields of one
+ *             per-sample record, which a data-parallel caller all-gathers with ONE collective)
  */
 int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, void *workspace, int64_t workspace_bytes,
                   const float *xv, const float *S, const float *dz_first, const float *dz_bi, const float *gbi,

@@ -188,3 +188,77 @@ def test_deepfm_two_ranks_equal_one_process():
     for _, rows, mlp in res:
         np.testing.assert_allclose(rows, ref_rows, rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(mlp, ref_mlp, rtol=1e-5, atol=1e-6)
+
+
+# ---- DeepFM on field owners (fmx.deep.OwnerDeepFMTrainer): tables and update work sharded, the MLP replicated ----
+def _deep_owner_run(rank, world, plan_world):
+    """DeepFM steps through fmx.OwnerDeepFMTrainer; world == 1 with plan_world == 2: ONE process holding every block of the
+    two-rank plan (the same pieces at the same positions).  -> (pieces {(col, base, rows): rows}, MLP parameters, losses)."""
+    import fmx
+    import torch.nn as nn
+    from fmx.owner import HipOwnerBackend
+    from fmx.plan import OwnerPlan, WholeOwnerPlan, export_columns, load_columns
+    torch.manual_seed(3)
+    H, L = 64, 2
+    layers = [nn.Linear(K if j == 0 else H, H).cuda() for j in range(L)]
+    first, second = _table(fmx).export_reference()                    # per-column weights of the shared start
+    plan = OwnerPlan(SIZES, K, plan_world, global_batch=B_LOCAL * 2)
+    use = plan if world == plan_world else WholeOwnerPlan(plan)
+    be = HipOwnerBackend(SIZES, K, fmx.Hyper(lr=0.01), "sgd", "logits", rank, world, max_local_batch=B_LOCAL * 2 // world, plan=use)
+    load_columns(be.table, first, second)
+    tr = fmx.OwnerDeepFMTrainer(be, layers, K, mlp_lr=0.01)
+    sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL) if world > 1 else slice(None)
+    data = [(torch.from_numpy(idx[sl].copy()).cuda(), torch.from_numpy(y[sl].copy()).cuda()) for idx, y in _batches(2)]
+    losses, tok = [], tr.prefetch(data[0][0])
+    for i, (idx_d, y_d) in enumerate(data):
+        losses.append(float(tr.step(idx_d, y_d, tok)))
+        tok = tr.prefetch(data[i + 1][0]) if i + 1 < len(data) else None
+    tr.finish()
+    torch.cuda.synchronize()
+    be.check_error_flag()
+    return {k_: v.numpy() for k_, v in export_columns(be.table, SIZES).items()}, tr.flat.cpu().numpy(), losses
+
+
+def _deep_owner_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "fm-for-online-recommendation_amd")]
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank,) + _deep_owner_run(rank, world, world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_deepfm_on_field_owners_two_ranks_equal_one_process():
+    """OwnerDeepFMTrainer at world size 2 (shared GPU, gloo with host staging): partial forward -> all-to-all -> finish -> MLP
+    section -> ONE all-reduce of the MLP gradients (side stream) + ONE all-gather of (S, dlogit, dL/dbi) records -> update of the
+    owned rows; against ONE process holding every block of the same plan.  The first step's table rows are the same bits (the
+    tables' additions are identical; the MLP has not been exchanged yet); afterwards the all-reduce's summation order shows:
+    1e-5 on values, as for the replicated trainer."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_deep_owner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref_pieces, ref_mlp, ref_losses = _deep_owner_run(0, 1, 2)
+    np.testing.assert_array_equal(res[0][2], res[1][2])                       # the replicated MLP: identical on both ranks
+    got = {}
+    for _, pieces, mlp, losses in res:
+        assert not (set(pieces) & set(got))                                   # every piece has one owner
+        got.update(pieces)
+        np.testing.assert_allclose(mlp, ref_mlp, rtol=1e-5, atol=1e-6)
+    assert set(got) == set(ref_pieces)
+    for key, rows in ref_pieces.items():
+        np.testing.assert_allclose(got[key], rows, rtol=1e-5, atol=1e-6, err_msg=f"piece {key}")
+    total = [a + b for a, b in zip(res[0][3], res[1][3])]                     # the ranks' shares add up to the global mean loss
+    np.testing.assert_allclose(total, ref_losses, rtol=1e-5)

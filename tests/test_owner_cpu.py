@@ -218,3 +218,148 @@ def test_owners_equal_one_owner_bit_for_bit(world):
             np.testing.assert_array_equal(state[k][~mine], st0[k][~mine], err_msg=f"rank {rank} {k}: foreign rows")  # ... nobody else touches them
     assert sum(r for _, _, r in owner_of) == sum(SIZES)
     assert any((st[k] != st0[k]).any() for k in ("zV", "zw"))                     # the steps did train
+
+
+# ---- DeepFM on field owners (fmx.deep.OwnerDeepFMTrainer) on CPU: the exchange logic of the scalable DeepFM step ----
+class OracleDeepOwnerBackend(OracleOwnerBackend):
+    """The owner backend for a weights-layout table under SGD plus what OwnerDeepFMTrainer needs: the finish without a loss, the
+    MLP section (PyTorch autograd here; fmx_mlp_section in the product) and the update from (S | dlogit | dL/dbi) records."""
+    kp = K
+    LR = 0.01
+
+    def _weights(self):
+        return self.st["V"], self.st["w"]
+
+    def partial_forward(self, idx_all, B_local):
+        V, w = self._weights()
+        rows, ok = self._occ(idx_all)
+        GB, G = rows.shape[0], rows.shape[0] // B_local
+        rec = np.zeros((G, self.nlb, B_local, 2 * K + 4), f32)
+        for lb in range(self.nlb):
+            S_slot = [np.zeros((GB, K), f32) for _ in range(self.sl)]
+            SS_slot = [np.zeros((GB, K), f32) for _ in range(self.sl)]
+            fo_slot = [np.zeros(GB, f32) for _ in range(self.sl)]
+            for p in range(self.np):
+                for s in range(self.sl):
+                    l = (lb * self.np + p) * self.sl + s
+                    m = ok[:, l]
+                    e = V[rows[:, l]]
+                    S_slot[s] = np.where(m[:, None], (S_slot[s] + e).astype(f32), S_slot[s])
+                    SS_slot[s] = np.where(m[:, None], (SS_slot[s] + e * e).astype(f32), SS_slot[s])
+                    fo_slot[s] = np.where(m, (fo_slot[s] + w[rows[:, l]]).astype(f32), fo_slot[s])
+            rec[:, lb, :, :K] = tree(S_slot).reshape(G, B_local, K)
+            rec[:, lb, :, K:2 * K] = tree(SS_slot).reshape(G, B_local, K)
+            rec[:, lb, :, 2 * K] = tree(fo_slot).reshape(G, B_local)
+        return torch.from_numpy(rec.reshape(-1, 2 * K + 4))
+
+    def finish_bi(self, mine):
+        m = mine.numpy()
+        S, SS, fo = tree([m[r, :, :K] for r in range(m.shape[0])]), tree([m[r, :, K:2 * K] for r in range(m.shape[0])]), \
+            tree([m[r, :, 2 * K] for r in range(m.shape[0])])
+        bi = ((S * S - SS) * f32(0.5)).astype(f32)
+        rec = np.zeros((S.shape[0], 2 * K + 4), f32)
+        rec[:, :K] = S
+        logit = (fo + bi.sum(axis=1, dtype=f32) + self.st["bias"]).astype(f32)
+        return torch.from_numpy(rec), torch.from_numpy(bi), torch.from_numpy(fo.astype(f32)), torch.from_numpy(logit)
+
+    def bias_weight(self):
+        return torch.tensor(float(self.st["bias"]))
+
+    def mlp_section(self, flat, gflat, k, hidden, n_layers, loss, bi, base, y, B, inv_b, lr_apply):
+        import torch.nn.functional as F
+        ws, off = [], 0
+        for l in range(n_layers):
+            n_in = k if l == 0 else hidden
+            W = flat[off:off + hidden * n_in].view(hidden, n_in).detach().clone().requires_grad_(True)
+            off += hidden * n_in
+            b = flat[off:off + hidden].detach().clone().requires_grad_(True)
+            off += hidden
+            ws += [W, b]
+        bi_l = bi[:, :k].detach().clone().requires_grad_(True)
+        base_l = base.detach().clone().requires_grad_(True)
+        x = bi_l
+        for l in range(n_layers):
+            x = F.relu(F.linear(x, ws[2 * l], ws[2 * l + 1]))
+        lo = F.binary_cross_entropy_with_logits(base_l + x.sum(1), y, reduction="sum") * inv_b
+        lo.backward()
+        gflat.copy_(torch.cat([p.grad.reshape(-1) for p in ws]))
+        if lr_apply:
+            flat.sub_(gflat, alpha=lr_apply)
+        return lo.detach().reshape(1), base_l.grad.contiguous(), bi_l.grad.contiguous()
+
+    def update_deep(self, idx_all, rec_all, fm_term, inv_b):
+        V, w = self._weights()
+        rows, ok = self._occ(idx_all)
+        rec = rec_all.numpy()
+        S, dz, gbi = np.ascontiguousarray(rec[:, :K]), np.ascontiguousarray(rec[:, K]), np.ascontiguousarray(rec[:, K + 4:])
+        G = (gbi + dz[:, None]).astype(f32) if fm_term else gbi
+        u, dV, dw = orc.flat_row_gradients(V, rows, ok.astype(f32), S, dz, G)
+        keep = u != self.scratch
+        u, dV, dw = u[keep], dV[keep], dw[keep]
+        V[u] = (V[u] - f32(self.LR) * dV).astype(f32)
+        w[u] = (w[u] - f32(self.LR) * dw).astype(f32)
+        self.st["bias"] = f32(self.st["bias"] - f32(self.LR) * dz.sum(dtype=f32))
+
+
+def _deep_state():
+    rng = np.random.default_rng(4)
+    offs = np.concatenate([[0], np.cumsum(SIZES)]).astype(np.int64)
+    R = int(offs[-1])
+    return dict(V=(rng.normal(size=(R + 1, K)) * 0.3).astype(f32), w=(rng.normal(size=R + 1) * 0.3).astype(f32), bias=f32(0.1)), offs
+
+
+def _deep_trainer(be):
+    import torch.nn as nn
+    from fmx.deep import OwnerDeepFMTrainer
+    torch.manual_seed(11)
+    layers = [nn.Linear(K if j == 0 else 32, 32) for j in range(2)]
+    return OwnerDeepFMTrainer(be, layers, K, mlp_lr=0.01)
+
+
+def _deep_owner_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st, offs = _deep_state()
+    be = OracleDeepOwnerBackend(st, offs, rank, world, make_plan(world))
+    tr = _deep_trainer(be)
+    sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL)
+    losses = [float(tr.step(torch.from_numpy(idx[sl].copy()), torch.from_numpy(y[sl].copy()))) for idx, y in make_batches(world)]
+    q.put((rank, losses, [f for f in be.fields if f[2]], {k: np.asarray(v).copy() for k, v in st.items()}, tr.flat.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_deepfm_on_field_owners_two_ranks_equal_one_rank():
+    """The scalable DeepFM step (fmx.deep.OwnerDeepFMTrainer) on CPU, world size 2 over gloo, oracle-backed compute: per step ONE
+    all-to-all and ONE record all-gather on the critical path plus ONE all-reduce of the flattened MLP gradients; against one
+    rank holding every block of the same plan.  First-step table rows identical; then 1e-5 (the all-reduce's summation order)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_deep_owner_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    st, offs = _deep_state()
+    one = _deep_trainer(OracleDeepOwnerBackend(st, offs, 0, 1, WholePlan(make_plan(world))))
+    ref_losses = [float(one.step(torch.from_numpy(idx), torch.from_numpy(y))) for idx, y in make_batches(world)]
+    st0, _ = _deep_state()
+    np.testing.assert_array_equal(res[0][4], res[1][4])                          # the replicated MLP: the same on both ranks
+    np.testing.assert_allclose(res[0][4], one.flat.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([a + b for a, b in zip(res[0][1], res[1][1])], ref_losses, rtol=1e-5)
+    for rank, losses, fields, state, _ in res:
+        mine = np.zeros(int(offs[-1]) + 1, dtype=bool)
+        for c, b, r in fields:
+            mine[int(offs[c]) + b:int(offs[c]) + b + r] = True
+        for k in ("V", "w"):
+            np.testing.assert_allclose(state[k][mine], st[k][mine], rtol=1e-5, atol=1e-6, err_msg=f"rank {rank} {k}")
+            np.testing.assert_array_equal(state[k][~mine], st0[k][~mine], err_msg=f"rank {rank} {k}: foreign rows")
+        np.testing.assert_allclose(state["bias"], st["bias"], rtol=1e-5)
+    assert (st["V"] != st0["V"]).any()
