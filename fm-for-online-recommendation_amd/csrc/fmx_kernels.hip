@@ -1583,6 +1583,21 @@ __global__ __launch_bounds__(256) void k_stream_read(const float4 *buf, int64_t 
   if (acc == 123456.789f) *sink = acc;  // keeps the loads live; practically never true
 }
 
+// k_gather_read: random-row read ceiling probe -- n rows of 64 or 128 bytes at pseudo-random (hashed) positions of a buffer,
+// 16 bytes per lane, LPR lanes per row: the access pattern of the forward gather with nothing else around it
+template <int LPR>
+__global__ __launch_bounds__(256) void k_gather_read(const float4 *buf, uint64_t n_rows, int64_t n, uint32_t seed, float *sink) {
+  const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+  const int q = threadIdx.x % LPR;
+  if (g >= n) return;
+  uint64_t h = ((uint64_t)g + seed) * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29;
+  h *= 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 32;
+  const float4 v = buf[(h % n_rows) * LPR + q];
+  if ((v.x + v.y) + (v.z + v.w) == 123456.789f) *sink = v.x;  // keeps the load live; practically never true
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host-side validation and dispatch
 // ------------------------------------------------------------------------------------------------------------
@@ -2805,6 +2820,20 @@ int fmx_mlp_hedge_fit(const fmx_mlp_t *mlp, float lr, float hedge_b, float hedge
   a.mode = MLP_MODE_HEDGE;
   a.inv_b = 1.0f / (float)B;
   return mlp_launch(mlp, a, B, kp, stream, "fmx_mlp_hedge_fit");
+}
+
+int fmx_gather_read(const void *buf, int64_t bytes, int32_t row_bytes, int64_t n_rows_read, uint32_t seed, float *sink, fmx_stream_t stream) {
+  if (!buf || !sink || bytes < 128 || n_rows_read < 1) return fail(FMX_ERR_ARG, "fmx_gather_read: bad buffer / count");
+  if (row_bytes != 64 && row_bytes != 128) return fail(FMX_ERR_ARG, "fmx_gather_read: rows of 64 or 128 bytes");
+  if (!aligned16(buf)) return fail(FMX_ERR_ALIGN, "fmx_gather_read: buffer must be 16-byte aligned");
+  const int lpr = row_bytes / 16;
+  const uint64_t n_rows = (uint64_t)bytes / (uint64_t)row_bytes;
+  const int64_t threads = n_rows_read * lpr;
+  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (lpr == 4) hipLaunchKernelGGL((k_gather_read<4>), grid, block, 0, st, static_cast<const float4 *>(buf), n_rows, n_rows_read, seed, sink);
+  else hipLaunchKernelGGL((k_gather_read<8>), grid, block, 0, st, static_cast<const float4 *>(buf), n_rows, n_rows_read, seed, sink);
+  return check_launch("k_gather_read");
 }
 
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream) {

@@ -19,7 +19,7 @@ EXPORTS = ["fmx_version", "fmx_last_error_string", "fmx_set_option", "fmx_sorted
            "fmx_mlp_section_workspace_bytes", "fmx_fm_online_run", "fmx_online_run_mlp", "fmx_mlp_forward_batch", "fmx_mlp_hedge_section",
            "fmx_sort_occurrences", "fmx_fm_update", "fmx_fm_step", "fmx_fm_stream", "fmx_stream_read",
            "fmx_fm_forward_partial", "fmx_fm_forward_finish", "fmx_sftrl_run", "fmx_sftrl_grid",
-           "fmx_comm_unique_id", "fmx_comm_create", "fmx_comm_destroy", "fmx_owner_prefetch", "fmx_owner_step"]
+           "fmx_gather_read", "fmx_comm_unique_id", "fmx_comm_create", "fmx_comm_destroy", "fmx_owner_prefetch", "fmx_owner_step"]
 
 
 I64_RETURNS = ("fmx_workspace_bytes", "fmx_mlp_section_workspace_bytes")   # byte counts: int64_t in include/fmx.h
@@ -91,6 +91,7 @@ def load():
     lib.fmx_fm_step.argtypes = [TP, HP, i32, i32, p, p, p, i32, f32, p, i64, FP, p, p]
     lib.fmx_fm_stream.argtypes = [TP, HP, i32, i32, p, p, i32, i32, f32, i32, p, i64, FP, p, C.POINTER(C.c_float), p]
     lib.fmx_stream_read.argtypes = [p, i64, p, p]
+    lib.fmx_gather_read.argtypes = [p, i64, i32, i64, C.c_uint32, p, p]
     lib.fmx_fm_online_run.argtypes = [TP, HP, i32, i32, p, p, p, i32, p, p, p, p]
     lib.fmx_comm_unique_id.argtypes = [p]
     lib.fmx_comm_create.argtypes = [p, i32, i32, p, i32, C.POINTER(C.c_void_p)]

@@ -160,7 +160,10 @@ class SFTRL_CCFM(FM_Base):
         _lib.check(lib.fmx_sftrl_grid(ptr(Xd), ptr(yd), n, D, d, S, ptr(ms), ptr(etas), m_max, float(m0._thres), 0 if task == "cls" else 1,
                                       ptr(BP), ptr(BN), ptr(counts), ptr(w), ptr(g_w), ptr(pred), ptr(status),
                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        if bool((status[:, 0] == 1).any().item()):
+        st_h = status.cpu()
+        if bool((st_h[:, 0] == 2).any()):
+            raise ValueError("a setting's num_feature lies outside [1, max]: not run (fmx_sftrl_grid status 2)")
+        if bool((st_h[:, 0] == 1).any()):
             raise ValueError("Nan contained")
         BPh, BNh, ch, ph = BP.cpu(), BN.cpu(), counts.cpu(), pred.cpu().numpy()
         out = []

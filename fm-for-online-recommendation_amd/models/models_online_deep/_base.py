@@ -238,6 +238,16 @@ class OnlineFMBase(nn.Module):
             elif t.dtype != dtype:
                 t = t.to(dtype)
             return t.contiguous()
+        # the reference's shapes only: [B, F], [B, F, 1] (Xi), or one sample [F] -- an array of another width whose size
+        # happens to divide by F must not be re-cut into wrong rows
+        shp = tuple(Xi.shape)
+        if not ((len(shp) == 2 and shp[1] == F) or (len(shp) == 3 and shp[1:] == (F, 1)) or shp == (F,) or shp == (F, 1)):
+            raise ValueError(f"Xi of shape {shp}: expected [B, {F}] ([B, {F}, 1], or one sample [{F}])")
+        if (torch.is_tensor(Xi) and Xi.dtype == torch.int64) or (isinstance(Xi, np.ndarray) and Xi.dtype.itemsize > 4):
+            # an index beyond int32 would wrap in the cast below and could land on a valid row: checked before the cast
+            big = bool((Xi >= 2 ** 31).any()) if torch.is_tensor(Xi) else bool((Xi >= 2 ** 31).any())
+            if big:
+                raise IndexError("index out of range in self")
         idx_d = to_dev(Xi, torch.int32).reshape(-1, F)
         xv_d = to_dev(Xv, torch.float32)
         if xv_d is not None:

@@ -399,7 +399,8 @@ int fmx_sftrl_run(const double *X, const double *y, int32_t N, int32_t D, int32_
  * per setting is latency-bound, 256 CUs run 256 settings in the time of one (the reference's notebooks try (eta, m) pairs one
  * run_experiment at a time).  ms [S] int32 (each <= m_max), etas [S] fp64 are device arrays.  Per setting s:
  *   BP, BN  [S][d * 2 * m_max]: setting s's sketch as [d, 2 ms[s]] row-major at the start of its slot;  counts [S, 2];
- *   w, g_w  [S, D] or both null;  pred_out [S, N];  status [S, 2]  -- everything else as fmx_sftrl_run, same limits.
+ *   w, g_w  [S, D] or both null;  pred_out [S, N];  status [S, 2]  -- everything else as fmx_sftrl_run, same limits;
+ *   status[s][0] = 2: ms[s] = status[s][1] lies outside [1, m_max] (the launch is sized for m_max): setting s was not run.
  * Every setting's result is bit-identical to its own fmx_sftrl_run. */
 int fmx_sftrl_grid(const double *X, const double *y, int32_t N, int32_t D, int32_t d, int32_t n_settings, const int32_t *ms,
                    const double *etas, int32_t m_max, double thres, int32_t task, double *BP, double *BN, int32_t *counts, double *w,
@@ -408,6 +409,10 @@ int fmx_sftrl_grid(const double *X, const double *y, int32_t N, int32_t D, int32
 /* Streaming read of `bytes` (multiple of 16) with 16-byte loads; sink [1] receives a checksum so the loads stay
  * live.  Used by bench.py to measure the HBM-read ceiling on the same GPU in the same run. */
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream);
+
+/* Random-row read probe (measurement aid, SURVEY.md section 8(d) "informational gather ceilings"): n_rows_read rows of row_bytes
+ * (64 or 128) at hashed positions of buf, 16 bytes per lane -- the forward gather's access pattern alone. */
+int fmx_gather_read(const void *buf, int64_t bytes, int32_t row_bytes, int64_t n_rows_read, uint32_t seed, float *sink, fmx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -82,14 +82,36 @@ def assert_within_f64(a, ref, floor, what, rtol=1e-5):
                            f"{float((err / np.maximum(tol, 1e-300)).max()):.2f}, max abs err {float(err.max()):.3e}")
 
 
-def assert_ftrl_step_within_f64(hip, ref, what=""):
+def assert_ftrl_step_within_f64(hip, ref, what="", before=None):
     """hip: the (z, n) state after the HIP step as dict(zV [R,k], nV, zw [R], nw, zb, nb); ref: flat_fm_step_f64's result
-    for the same step.  Touched rows within 1e-5 + floor of the float64 step, untouched rows bit-identical."""
+    for the same step.  Touched rows within 1e-5 + floor of the float64 step, untouched rows bit-identical.
+    before: the state the step started from -- then the STEP itself is checked too, |(hip - before) - (ref - before)| <=
+    1e-5 |ref - before| + floor: at the headline batch a rarely hit row moves by ~1e-4 in z with |z| ~ 10, inside 1e-5 |z|, so
+    the check on values alone would pass a skipped update; the check on the step does not (the floors are those of the
+    step's own terms)."""
     u, new, fl = ref["urows"], ref["new"], ref["floor"]
     for kk in ("zV", "nV", "zw", "nw"):
         assert_within_f64(np.asarray(hip[kk])[u], new[kk][u], fl[kk], f"{what}{kk}")
+        if before is not None:
+            b0 = np.asarray(before[kk], np.float64)[u]
+            assert_within_f64(np.asarray(hip[kk], np.float64)[u] - b0, new[kk][u] - b0, fl[kk], f"{what}{kk} (the step)")
         mask = np.ones(len(new[kk]), dtype=bool)
         mask[u] = False
         np.testing.assert_array_equal(np.asarray(hip[kk])[mask], new[kk][mask].astype(np.float32), err_msg=f"{what}{kk} untouched rows")
     assert_within_f64(hip["zb"], new["zb"], fl["zb"], f"{what}zb")
     assert_within_f64(hip["nb"], new["nb"], fl["nb"], f"{what}nb")
+
+
+def oracle_float64():
+    """The oracle's restatement evaluated in FLOAT64: the same source (oracle/fm_oracle.py) with its working type `f32` bound to
+    numpy.float64, as a module of its own.  What an fp32 implementation approximates, free of any fp32 summation order -- the
+    reference for "within 1e-5 of the float64 value + the fp32 rounding floor" checks of the paths the oracle only has in fp32
+    (Hedge backprop).  Test infrastructure, like the oracle itself."""
+    import types
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "fm_oracle.py")
+    src = open(path).read()
+    assert src.count("f32 = np.float32") == 1
+    mod = types.ModuleType("fm_oracle_f64")
+    mod.__file__ = path
+    exec(compile(src.replace("f32 = np.float32", "f32 = np.float64"), path, "exec"), mod.__dict__)
+    return mod

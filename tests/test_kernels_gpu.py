@@ -293,10 +293,10 @@ def test_step_ftrl(fmx, B, k):
     ref = orc.flat_fm_step_f64(st0, pr["rows"], x, pr["y"], "logits", "ftrl", h)
     assert_within_f64(float(eng.loss_out.item()), ref["loss"], ref["floor"]["loss"], "loss")
     zV, nV, zw, nw = [a.numpy() for a in t.export_ftrl_state()]
-    assert_ftrl_step_within_f64(dict(zV=zV, nV=nV, zw=zw, nw=nw, zb=t.bias[0].item(), nb=t.bias[1].item()), ref)
+    assert_ftrl_step_within_f64(dict(zV=zV, nV=nV, zw=zw, nw=nw, zb=t.bias[0].item(), nb=t.bias[1].item()), ref, before=st0)
     # and the fp32 oracle step (what bench.py's cpu_baseline times) sits inside the same band
     out = orc.flat_fm_step(st, pr["rows"], x, pr["y"], "logits", "ftrl", h)
-    assert_ftrl_step_within_f64(st, ref, "fp32 oracle ")
+    assert_ftrl_step_within_f64(st, ref, "fp32 oracle ", before=st0)
     np.testing.assert_array_equal(out["urows"], ref["urows"])
 
 
@@ -371,7 +371,7 @@ def test_full_size_criteo(fmx, rule):
     ref = orc.flat_fm_step_f64(st0, pr["rows"], x, pr["y"], "logits", "ftrl", h)
     assert_within_f64(float(eng.loss_out.item()), ref["loss"], ref["floor"]["loss"], "loss")
     zV, nV, zw, nw = [a.numpy() for a in t.export_ftrl_state()]
-    assert_ftrl_step_within_f64(dict(zV=zV, nV=nV, zw=zw, nw=nw, zb=t.bias[0].item(), nb=t.bias[1].item()), ref)
+    assert_ftrl_step_within_f64(dict(zV=zV, nV=nV, zw=zw, nw=nw, zb=t.bias[0].item(), nb=t.bias[1].item()), ref, before=st0)
     # size-independent properties: n never decreases, sortedness of every list, the cached weights are the derived ones
     assert (nV >= st0["nV"]).all()
     srt = eng.sorted.cpu().numpy().view(np.uint32)
@@ -462,7 +462,7 @@ def test_one_exact_step_of_32768_samples_with_an_18_bit_field(fmx):
     ref = orc.flat_fm_step_f64(st0, pr["rows"], np.ones((B, len(sizes)), np.float32), pr["y"], "logits", "ftrl", h)
     assert_within_f64(float(eng.loss_out.item()), ref["loss"], ref["floor"]["loss"], "loss")
     zV, nV, zw, nw = [a.numpy() for a in t.export_ftrl_state()]
-    assert_ftrl_step_within_f64(dict(zV=zV, nV=nV, zw=zw, nw=nw, zb=t.bias[0].item(), nb=t.bias[1].item()), ref)
+    assert_ftrl_step_within_f64(dict(zV=zV, nV=nV, zw=zw, nw=nw, zb=t.bias[0].item(), nb=t.bias[1].item()), ref, before=st0)
     srt = eng.sorted.cpu().numpy().view(np.uint32)
     assert srt.shape[0] == 6 and (np.diff(srt.astype(np.int64), axis=1) >= 0).all()
     assert ((srt != 0xFFFFFFFF).sum(axis=1)[[1, 2]].sum()) == B          # every sample is in exactly one piece of field 1
@@ -536,7 +536,7 @@ def test_step_shape_sweep(fmx, F, k, B):
         ref = orc.flat_fm_step_f64(st0, pr["rows"], x, pr["y"], "sigmoid", "ftrl", h)
         assert_within_f64(float(eng.loss_out.item()), ref["loss"], ref["floor"]["loss"], "loss")
         zV, nV, zw, nw = [a.numpy() for a in t.export_ftrl_state()]
-        assert_ftrl_step_within_f64(dict(zV=zV, nV=nV, zw=zw, nw=nw, zb=t.bias[0].item(), nb=t.bias[1].item()), ref)
+        assert_ftrl_step_within_f64(dict(zV=zV, nV=nV, zw=zw, nw=nw, zb=t.bias[0].item(), nb=t.bias[1].item()), ref, before=st0)
         # the cached weights equal the weights derived from the stored (z, n)
         Vc = t.rows[:, :k].cpu().numpy()
         np.testing.assert_allclose(Vc, orc.ftrl_weight(zV, nV, **h), rtol=2e-6, atol=1e-7)

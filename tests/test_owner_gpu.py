@@ -172,7 +172,7 @@ def test_the_whole_table_step_meets_the_oracle(sizes, G, B):
         got["zV"][lo:lo + r], got["nV"][lo:lo + r] = pr[:, zo:zo + k], pr[:, zo + kp:zo + kp + k]
         got["zw"][lo:lo + r], got["nw"][lo:lo + r] = pr[:, kp + 1], pr[:, kp + 2]
     got["zb"], got["nb"] = t_ref.bias[0].item(), t_ref.bias[1].item()
-    assert_ftrl_step_within_f64(got, ref)
+    assert_ftrl_step_within_f64(got, ref, before=st0)
     owners, losses = _emulate(fmx, plan, sizes, k, B, "ftrl", batches)
     assert all(l == ref_losses[0] for l in losses[0])
     whole = _pieces(t_ref)
@@ -400,7 +400,7 @@ def test_frappe_shaped_10m_row_table_split_over_two_owners():
     hip = dict(zV=np.stack([rows1[key][zo:zo + k] for key in keys]), nV=np.stack([rows1[key][zo + kp:zo + kp + k] for key in keys]),
                zw=np.array([rows1[key][kp + 1] for key in keys]), nw=np.array([rows1[key][kp + 2] for key in keys]),
                zb=float(bias1[0]), nb=float(bias1[1]))
-    assert_ftrl_step_within_f64(hip, ref)
+    assert_ftrl_step_within_f64(hip, ref, before=st0)
 
 
 def test_rccl_collectives_of_a_step_with_one_rank():
