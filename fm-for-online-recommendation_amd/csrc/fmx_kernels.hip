@@ -1856,9 +1856,16 @@ void launch_update_pair(const UpdArgs &a, int rule, bool has_gbi, hipStream_t st
 }
 
 template <int E>
-void launch_sort(const SortArgs &a, hipStream_t st) {
+void launch_sort(SortArgs a, hipStream_t st) {
   const int threads = a.Bp / E;
-  const uint32_t lds = (uint32_t)(a.Bp * sizeof(uint32_t));
+  uint32_t lds = (uint32_t)(a.Bp * sizeof(uint32_t));
+  // fields of at most 511 rows take one counting pass inside the same launch (fmx_sort.inc, radix_field): on the Criteo list 24
+  // of the 39 fields -- the launch's length is still the network's (the 15 larger fields), its chip time is not
+  if (a.Bp <= RADIX_SMALL_WIDTH && threads >= 64) {
+    a.small_bits = RADIX_SMALL_BITS;
+    const uint32_t need = (uint32_t)radix_small_lds_bytes(a.Bp, threads);
+    if (need > lds) lds = need;
+  }
   const int grid = a.n_batches >= 8 ? 8 * a.F * ((a.n_batches + 7) / 8) : a.F * a.n_batches;
   hipLaunchKernelGGL((k_sort_occ<E>), dim3(grid), dim3(threads), lds, st, a);
 }
@@ -1915,6 +1922,7 @@ int sort_impl(const fmx_table_t *table, const int32_t *idx, int32_t B, uint32_t 
   a.B = B;
   a.F = n_sort_fields(table);
   a.Fi = n_cols(table);
+  a.small_bits = 0;
   a.fcols = table->field_cols;
   a.fbase = table->field_base;
   a.Bp = fmx_sorted_width(B);
@@ -2464,11 +2472,12 @@ int fmx_fm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
     int ahead = tune().sort_ahead;
     if (ahead < 1) ahead = 1;
     if (ahead > SORT_AHEAD_MAX) ahead = SORT_AHEAD_MAX;
-    // group g holds min(2^g, ahead) batches: the first sort (one batch) runs beside the first forward pass and exposes only
-    // its own ~19 us instead of a whole group's 30; the pipeline is at full depth from the fourth group on.  Group g uses
-    // half (g & 1) of the ring of 2 * ahead sorted buffers.
+    // the first group holds up to 4 batches, the others `ahead` (8): one launch sorts four batches in about the time of one (one
+    // workgroup per field and batch: 18.4 against 17.1 us, tools/micro/sort_bench.hip), so the first update waits no longer than
+    // behind a one-batch group, and a short call issues three sort launches and their events instead of five while the device
+    // is still waiting for the host.  Group g uses half (g & 1) of the ring of 2 * ahead sorted buffers.
     auto group_size = [&](int g, int first_step) {
-      int n = g < 3 ? (1 << g) : ahead;
+      int n = g == 0 ? 4 : ahead;
       if (n > ahead) n = ahead;
       if (n > n_steps - first_step) n = n_steps - first_step;
       return n;

@@ -49,8 +49,17 @@ int main(int argc, char **argv) {
   auto grid = [&](int nb) { return nb >= 8 ? 8 * F * ((nb + 7) / 8) : F * nb; };
   auto run_bitonic = [&](int nb, uint32_t *dst) { SortArgs x = a; x.n_batches = nb; x.sorted = dst; hipLaunchKernelGGL((k_sort_occ<4>), dim3(grid(nb)), dim3(Bp / 4), Bp * 4, 0, x); };
   auto run_radix = [&](int nb, uint32_t *dst) { SortArgs x = a; x.n_batches = nb; x.sorted = dst; hipLaunchKernelGGL(k_sort_radix, dim3(grid(nb)), dim3(RADIX_THREADS < Bp ? RADIX_THREADS : Bp), rlds, 0, x, d_starts, 2048); };
+  const size_t hlds = radix_small_lds_bytes(Bp, Bp / 4) > (size_t)Bp * 4 ? radix_small_lds_bytes(Bp, Bp / 4) : (size_t)Bp * 4;
+  auto run_hybrid = [&](int nb, uint32_t *dst) { SortArgs x = a; x.n_batches = nb; x.sorted = dst; x.small_bits = RADIX_SMALL_BITS; hipLaunchKernelGGL((k_sort_occ<4>), dim3(grid(nb)), dim3(Bp / 4), hlds, 0, x); };
   auto run_floor = [&](int nb, uint32_t *dst) { SortArgs x = a; x.n_batches = nb; x.sorted = dst; hipLaunchKernelGGL(k_floor, dim3(grid(nb)), dim3(Bp / 4), 0, 0, x); };
   // ---- identical lists ----
+  run_bitonic(NB, d_a); run_hybrid(NB, d_b); CK(hipDeviceSynchronize());
+  {
+    std::vector<uint32_t> ha(NB * per), hb(NB * per);
+    CK(hipMemcpy(ha.data(), d_a, ha.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), d_b, hb.size() * 4, hipMemcpyDeviceToHost));
+    size_t diff = 0; for (size_t i = 0; i < ha.size(); ++i) diff += ha[i] != hb[i];
+    printf("hybrid (k_sort_occ, small fields by one counting pass) vs bitonic: %zu words differ\n", diff);
+  }
   run_bitonic(NB, d_a); run_radix(NB, d_b); CK(hipDeviceSynchronize());
   std::vector<uint32_t> ha(NB * per), hb(NB * per);
   CK(hipMemcpy(ha.data(), d_a, ha.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), d_b, hb.size() * 4, hipMemcpyDeviceToHost));
@@ -88,6 +97,6 @@ int main(int argc, char **argv) {
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("  %-10s %d batch(es) per launch: %7.2f us per launch\n", what, nb, ms * 1e3 / reps);
   };
-  for (int nb : {1, 2, 4, 8}) { time_it("bitonic", run_bitonic, nb); time_it("radix", run_radix, nb); time_it("floor", run_floor, nb); }
+  for (int nb : {1, 2, 4, 8}) { time_it("bitonic", run_bitonic, nb); time_it("radix", run_radix, nb); time_it("hybrid", run_hybrid, nb); time_it("floor", run_floor, nb); }
   return 0;
 }
