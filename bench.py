@@ -404,6 +404,8 @@ def main():
     ap.add_argument("--loop-only", action="store_true", help="only the timed online loop (no measuring pass, no spread pass): "
                                                              "what tools/profile_round.sh traces for the in-loop kernel durations")
     ap.add_argument("--row-stride", type=int, default=0)
+    ap.add_argument("--owner-path", default="native", choices=["native", "torch"],
+                    help="--gpus N, field owners: fmx_owner_step (one C call per step, own RCCL communicator) or torch.distributed collectives")
     ap.add_argument("--mp-mode", default="owner", choices=["owner", "replicated"],
                     help="N > 1: 'owner' = field-owner mode (fmx.owner: table and update work shard over the ranks), "
                          "'replicated' = every rank keeps the whole table and repeats the global update (fmx.DataParallelFM)")
@@ -534,7 +536,27 @@ def main():
         # ---- N GPUs: exact data parallelism (fmx.DataParallelFM): forward on the local slice, all-gather of the
         #      low-rank factors (idx, S, dlogit) over RCCL, identical row-reduced update of the replicas ----
         dp = None if owner_mode else fmx.DataParallelFM(fmx.HipBackend(eng, hyper, RULE, "logits"))
-        fo = FieldOwnerFM(obe) if owner_mode else None
+        fo, owner_path = None, None
+        work = torch.cuda.Stream(device=dev)          # not the legacy default stream (slow to enqueue on)
+        if owner_mode:
+            # the step as ONE C call with the library's own RCCL communicator (fmx_owner_step) where every rank has a GPU of its
+            # own; agreed on by all ranks (a rank that cannot set it up takes everybody to the torch.distributed form of the
+            # same step: identical results, more host time).  --owner-path torch forces the latter.
+            ok = 0
+            if not rehearsal and args.owner_path == "native":
+                try:
+                    from fmx.owner import NativeOwnerFM
+                    fo = NativeOwnerFM(obe, stream=work)
+                    ok = 1
+                except Exception as exc:              # e.g. librccl.so.1 not loadable
+                    print(f"[bench] rank {rank}: fmx_owner_step unavailable ({exc!r})", file=sys.stderr)
+            flag = torch.tensor([ok], device="cpu" if rehearsal else dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 1:
+                owner_path = "fmx_owner_step (one C call per step, the library's own RCCL communicator)"
+            else:
+                fo = FieldOwnerFM(obe)
+                owner_path = "FieldOwnerFM (torch.distributed collectives between the kernels' calls)"
 
         def run_owner(n, first=0):
             # the index all-gather, the column pick and the sort of the owned fields run two steps ahead on the prefetch stream
@@ -564,7 +586,6 @@ def main():
                 j = (first + s) % N_POOL
                 out = dp.step(idx_pool[j], y_pool[j])
             return out
-        work = torch.cuda.Stream(device=dev)          # not the legacy default stream (slow to enqueue on)
         with torch.cuda.stream(work):
             run(args.warmup)
             barrier()
@@ -589,8 +610,10 @@ def main():
                    if owner_mode else
                    f"dp{world}: replicated table, all-gather of (idx, S, dlogit), identical update on every replica (exact)")
     if world > 1:
-        sub = (fo if owner_mode else dp)._sub_steps(BATCH)
+        sub = 1 if (owner_mode and not hasattr(fo, "_sub_steps")) else (fo if owner_mode else dp)._sub_steps(BATCH)
         parallelism += f"; {sub} exact update(s) per step (global batch {BATCH * world})"
+        if owner_path:
+            parallelism += "; step issued through " + owner_path
 
     if stream_gbps is None:
         stream_gbps = stream_read_probe(fmx, torch, dev)
