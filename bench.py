@@ -577,14 +577,14 @@ def main():
             # a step is one exact update (two global sorts in flight: one alone is as long as the step or longer), one
             # step (= all its sub-steps) ahead when the global batch is split
             depth = 2 if dp._sub_steps(BATCH) == 1 else 1
-            out = None
+            out, tokens = None, {}
             for d in range(min(depth, n)):
-                dp.prefetch(idx_pool[(first + d) % N_POOL])
+                tokens[d] = dp.prefetch(idx_pool[(first + d) % N_POOL])
             for s in range(n):
                 if s + depth < n:
-                    dp.prefetch(idx_pool[(first + s + depth) % N_POOL])
+                    tokens[s + depth] = dp.prefetch(idx_pool[(first + s + depth) % N_POOL])
                 j = (first + s) % N_POOL
-                out = dp.step(idx_pool[j], y_pool[j])
+                out = dp.step(idx_pool[j], y_pool[j], tokens.pop(s, None))
             return out
         with torch.cuda.stream(work):
             run(args.warmup)

@@ -45,17 +45,18 @@ class HipDeepBackend:
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             e.sort(idx_g)
-        self._sorted_for = idx_g.data_ptr()
+        self._sorted = object()          # a handle for THIS sort: update() takes it back (not the tensor's address, which can be recycled)
+        return self._sorted
 
-    def update(self, idx_g, S_g, dz_g, gbi_g, fm_term, inv_b):
+    def update(self, idx_g, S_g, dz_g, gbi_g, fm_term, inv_b, sorted_handle=None):
         e = self.e
         GB = idx_g.shape[0]
         e._ensure(GB)
-        if getattr(self, "_sorted_for", None) == idx_g.data_ptr() and getattr(self, "_side", None) is not None:
+        if sorted_handle is not None and sorted_handle is getattr(self, "_sorted", None):
             torch.cuda.current_stream(e.device).wait_stream(self._side)
         else:
             e.sort(idx_g)
-        self._sorted_for = None
+        self._sorted = None
         e.update(self.hyper, self.rule, GB, None, dz_g, dz_g if fm_term else None, gbi_g, inv_b=inv_b, with_loss=False, S=S_g)
 
 
@@ -149,8 +150,7 @@ class DeepFMTrainer:
         B = idx_local.shape[0]
         inv_b = 1.0 / (B * self.world)
         idx_g = self._gathered("idx", idx_local)
-        if hasattr(self.backend, "start_sort") and idx_g.is_cuda:
-            self.backend.start_sort(idx_g)
+        handle = self.backend.start_sort(idx_g) if (hasattr(self.backend, "start_sort") and idx_g.is_cuda) else None
         S, bi, sfirst, logit_fm = self.backend.forward(idx_local)
         base_in = logit_fm if self.fm_term else sfirst + self.backend.bias()
         applied = False
@@ -175,7 +175,10 @@ class DeepFMTrainer:
         S_g = self._gathered("S", S)
         dz_g = self._gathered("dz", dz)
         gbi_g = self._gathered("gbi", gbi)
-        self.backend.update(idx_g, S_g.contiguous(), dz_g.contiguous(), gbi_g, self.fm_term, inv_b)
+        if handle is not None:
+            self.backend.update(idx_g, S_g.contiguous(), dz_g.contiguous(), gbi_g, self.fm_term, inv_b, sorted_handle=handle)
+        else:
+            self.backend.update(idx_g, S_g.contiguous(), dz_g.contiguous(), gbi_g, self.fm_term, inv_b)
         if self.native:
             if not applied:
                 self.flat.sub_(flat, alpha=self.mlp_lr)

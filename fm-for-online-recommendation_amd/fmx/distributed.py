@@ -115,22 +115,27 @@ class DataParallelFM:
             dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         return out
 
-    def step(self, idx_local, y_local):
+    def step(self, idx_local, y_local, token=None):
         """One exact data-parallel step.  idx_local [B,F] int32 and y_local [B] fp32 are this rank's slice; the global
-        batch is the rank-major concatenation.  Returns the global mean-loss tensor [1] (of the last sub-step, see below).
+        batch is the rank-major concatenation.  token: what prefetch() returned for this batch (the gathered indices and the
+        global sort of every sub-step are then already under way), or None.  Returns the global mean-loss tensor [1] (of the
+        last sub-step, see below).
 
-        When G * B exceeds what one exact step can take (backend.max_global_batch: 16,384 for the Criteo vocabulary,
-        whose largest field needs 18 index bits), the batch is processed as consecutive exact steps over equal slices of
-        every rank's samples -- still exact online learning, with a smaller global batch per update."""
+        When G * B exceeds what one exact step can take (backend.max_global_batch), the batch is processed as consecutive exact
+        steps over equal slices of every rank's samples -- still exact online learning, with a smaller global batch per update."""
         B = idx_local.shape[0]
         n_sub = self._sub_steps(B)
+        pref = self._pref.pop(id(token), None) if (token is not None and hasattr(self, "_pref")) else None
+        if pref is not None and (pref[2] != B or len(pref[1]) != n_sub):
+            self._release(pref[1])
+            pref = None
         if n_sub > 1:
             out = None
             Bs = B // n_sub
             for j in range(n_sub):
-                out = self._step(idx_local[j * Bs:(j + 1) * Bs], y_local[j * Bs:(j + 1) * Bs])
+                out = self._step(idx_local[j * Bs:(j + 1) * Bs], y_local[j * Bs:(j + 1) * Bs], pref[1][j] if pref else None)
             return out
-        return self._step(idx_local, y_local)
+        return self._step(idx_local, y_local, pref[1][0] if pref else None)
 
     def _sub_steps(self, B):
         cap = getattr(self.backend, "max_global_batch", None)
@@ -139,26 +144,44 @@ class DataParallelFM:
             n_sub *= 2
         return n_sub
 
+    def _release(self, parts):
+        """Give prefetched slots back unused (their buffers are free once the prefetch stream has passed them)."""
+        for _, slot, _ in parts:
+            st = self._pf_streams[slot]
+            st[2].record(st[0])
+
+    def cancel(self, token):
+        pref = self._pref.pop(id(token), None) if (token is not None and hasattr(self, "_pref")) else None
+        if pref is not None:
+            self._release(pref[1])
+
     def prefetch(self, idx_next):
         """Gather and sort a LATER step's indices now (they do not depend on the weights): the index all-gather and the
         global occurrence sort of every sub-step run on a prefetch stream of their own, into a slot (gathered-index
-        buffer + workspace) of their own, beside the steps in front of them.  Call it before the step it should overlap
-        with; up to backend.N_SLOTS sub-steps may be in flight (slots are reused in order)."""
+        buffer + workspace) of their own, beside the steps in front of them.  Returns a TOKEN to hand to step() with that
+        batch (or to cancel()); None when the backend cannot or no slot is free (step() then gathers and sorts by itself).
+        Up to backend.N_SLOTS sub-steps may be in flight.  (Rounds 1-2 matched prepared work by the batch tensor's address: a
+        recycled address with new contents would have consumed a stale sorted list.)"""
         if not (idx_next.is_cuda and hasattr(self.backend, "start_sort")):
-            return
+            return None
         if not hasattr(self, "_pref"):
             self._pref, self._next_slot, self._pf_streams = {}, 0, {}
         B = idx_next.shape[0]
         n_sub = self._sub_steps(B)
         Bs = B // n_sub
         n_slots = getattr(self.backend, "N_SLOTS", 1)
-        if len(self._pref) + n_sub > n_slots:
-            return                                            # no free slot: the step will gather and sort by itself
+        busy = {slot for _, parts, _ in self._pref.values() for _, slot, _ in parts}
+        if len(busy) + n_sub > n_slots:
+            return None                                       # no free slot: the step will gather and sort by itself
         dev = idx_next.device
         cur = torch.cuda.current_stream(dev)
+        parts = []
         for j in range(n_sub):
             part = idx_next[j * Bs:(j + 1) * Bs] if n_sub > 1 else idx_next
             slot = self._next_slot
+            while slot in busy:
+                slot = (slot + 1) % n_slots
+            busy.add(slot)
             self._next_slot = (slot + 1) % n_slots
             st = self._pf_streams.get(slot)
             if st is None:
@@ -169,11 +192,11 @@ class DataParallelFM:
                 if shared is None:
                     shared = self._pf_streams[("stream", slot % 2)] = torch.cuda.Stream(device=dev)
                 st = self._pf_streams[slot] = (shared, torch.cuda.Event(), torch.cuda.Event())
-                st[0].wait_stream(cur)
             else:
                 st[0].wait_event(st[2])                       # the update that last used this slot has run
+            st[0].wait_stream(cur)                            # whatever wrote idx_next (an H2D copy, a refill) comes first
             pf, ready = st[0], st[1]
-            if self.world > 1:                                # the collective goes to whatever stream is current
+            if self.world > 1 or os.environ.get("FMX_FORCE_COLLECTIVES") == "1":   # the collective goes to whatever stream is current
                 with torch.cuda.stream(pf):
                     idx_g = self._gathered(f"idx_slot{slot}", part)
                     self.backend.start_sort(idx_g, slot, stream=pf)
@@ -181,14 +204,14 @@ class DataParallelFM:
                 idx_g = part
                 self.backend.start_sort(idx_g, slot, stream=pf)
             ready.record(pf)
-            self._pref[part.data_ptr()] = (idx_g, slot, ready)
+            parts.append((idx_g, slot, ready))
+        token = object()
+        self._pref[id(token)] = (token, parts, B)
+        return token
 
-    def _step(self, idx_local, y_local):
+    def _step(self, idx_local, y_local, pref=None):
         B = idx_local.shape[0]
         inv_b = 1.0 / (B * self.world)
-        pref = getattr(self, "_pref", {}).pop(idx_local.data_ptr(), None) if idx_local.is_cuda else None
-        if pref is not None and pref[0].shape[0] != B * self.world:
-            pref = None
         cur = torch.cuda.current_stream(idx_local.device) if idx_local.is_cuda else None   # looked up once per step
         kw = {"stream": cur} if cur is not None and getattr(self.backend, "takes_stream", False) else {}
         rec = self.backend.forward(idx_local, y_local, inv_b, **kw)

@@ -82,10 +82,10 @@ def _worker(rank, world, port, q):
     losses = []
     sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL)
     batches = [(torch.from_numpy(idx[sl].copy()), torch.from_numpy(y[sl].copy())) for idx, y in make_batches(world)]
+    tok = None
     for i, (idx_t, y_t) in enumerate(batches):
-        losses.append(float(dp.step(idx_t, y_t)[0]))
-        if i + 1 < len(batches) and i % 2 == 0:
-            dp.prefetch(batches[i + 1][0])              # every other step takes the prefetched-index path
+        losses.append(float(dp.step(idx_t, y_t, tok)[0]))
+        tok = dp.prefetch(batches[i + 1][0]) if (i + 1 < len(batches) and i % 2 == 0) else None   # (CPU tensors: no token, the in-line path)
     q.put((rank, losses, {k: np.asarray(v).copy() for k, v in st.items()}))
     dist.barrier()
     dist.destroy_process_group()

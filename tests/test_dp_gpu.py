@@ -43,10 +43,10 @@ def _run(rank, world):
     sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL) if world > 1 else slice(None)
     data = [eng.to_device(idx[sl], None, y[sl]) for idx, y in _batches(2)]
     losses = []
+    tok = None
     for i, (idx_d, _, y_d) in enumerate(data):
-        losses.append(float(dp.step(idx_d, y_d)[0]))
-        if i + 1 < len(data):
-            dp.prefetch(data[i + 1][0])
+        losses.append(float(dp.step(idx_d, y_d, tok)[0]))
+        tok = dp.prefetch(data[i + 1][0]) if i + 1 < len(data) else None
     torch.cuda.synchronize()
     eng.check_error_flag()
     return losses, t.rows.cpu().numpy(), t.bias.cpu().numpy()
@@ -115,12 +115,14 @@ def test_prefetch_slots_and_sub_steps_equal_plain_steps(cap, depth):
     losses = []
     work = torch.cuda.Stream()
     with torch.cuda.stream(work):
-        for d in range(depth):
-            dp.prefetch(data[d][0])
+        tokens = {d: dp.prefetch(data[d][0]) for d in range(depth)}
+        spare = dp.prefetch(data[-1][0])                       # a token given back unused (or None when no slot is free)
+        dp.cancel(spare)
         for i, (idx_d, _, y_d) in enumerate(data):
             if i + depth < len(data):
-                dp.prefetch(data[i + depth][0])
-            losses.append(dp.step(idx_d, y_d).clone())
+                tokens[i + depth] = dp.prefetch(data[i + depth][0])   # (None when every slot is taken: that step gathers and sorts in line)
+            # the tensor handed to step() is a fresh COPY at another address: prepared work is found by its token, not by the address
+            losses.append(dp.step(idx_d.clone(), y_d, tokens.pop(i, None)).clone())
     torch.cuda.synchronize()
     eng.check_error_flag()
     assert not dp._pref, "every prefetched batch must have been consumed"

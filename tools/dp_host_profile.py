@@ -14,11 +14,11 @@ eng = fmx.FMEngine(t, max_batch=B)
 dp = fmx.DataParallelFM(fmx.HipBackend(eng, fmx.Hyper(**bench.HYPER), "ftrl", "logits"))
 work = torch.cuda.Stream()
 def run(n):
-    dp.prefetch(idx_pool[0])
+    tok = dp.prefetch(idx_pool[0])
     for s in range(n):
-        if s + 1 < n:
-            dp.prefetch(idx_pool[(s + 1) % n_pool])
-        dp.step(idx_pool[s % n_pool], y_pool[s % n_pool])
+        nxt = dp.prefetch(idx_pool[(s + 1) % n_pool]) if s + 1 < n else None
+        dp.step(idx_pool[s % n_pool], y_pool[s % n_pool], tok)
+        tok = nxt
 with torch.cuda.stream(work):
     run(50)
     torch.cuda.synchronize()

@@ -18,12 +18,11 @@ for depth in (0, 1, 2):
     work = torch.cuda.Stream()
     with torch.cuda.stream(work):
         def run(n):
-            for d in range(min(depth, n)):
-                dp.prefetch(idx_pool[d % n_pool])
+            tokens = {d: dp.prefetch(idx_pool[d % n_pool]) for d in range(min(depth, n))}
             for s in range(n):
                 if depth and s + depth < n:
-                    dp.prefetch(idx_pool[(s + depth) % n_pool])
-                dp.step(idx_pool[s % n_pool], y_pool[s % n_pool])
+                    tokens[s + depth] = dp.prefetch(idx_pool[(s + depth) % n_pool])
+                dp.step(idx_pool[s % n_pool], y_pool[s % n_pool], tokens.pop(s, None))
         run(20)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

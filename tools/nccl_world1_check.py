@@ -80,10 +80,11 @@ t2 = fmx.FlatTable(sizes, K, layout="ftrl", device=dev, ftrl=B.HYPER)
 init(t2)
 dp = fmx.DataParallelFM(fmx.HipBackend(fmx.FMEngine(t2, max_batch=BATCH), hyper, "ftrl", "logits"))
 with torch.cuda.stream(work):
+    tok = None
     for s in range(STEPS):
-        if s + 1 < STEPS:
-            dp.prefetch(idx_pool[(s + 1) % NP])
-        out = dp.step(idx_pool[s % NP], y_pool[s % NP])
+        nxt = dp.prefetch(idx_pool[(s + 1) % NP]) if s + 1 < STEPS else None
+        out = dp.step(idx_pool[s % NP], y_pool[s % NP], tok)
+        tok = nxt
 torch.cuda.synchronize()
 assert torch.equal(t2.rows, ref.rows), "replicated mode over RCCL (one rank): rows differ"
 print("replicated mode, nccl, 1 rank, forced collectives: bit-identical; last loss %.6f" % float(out.reshape(-1)[0]), flush=True)
