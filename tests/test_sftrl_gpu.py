@@ -124,3 +124,35 @@ def test_gpu_sketched_ftrl_grid_equals_single_runs(name, task, golden_dir, capsy
         if (lr, m) == (0.05, 4):
             np.testing.assert_allclose(pred, z[f"{task}/{name}/pred"].reshape(pred.shape), rtol=1e-7, atol=1e-9)
     capsys.readouterr()
+
+
+def test_grid_refuses_a_sketch_size_beyond_the_launch():
+    """fmx_sftrl_grid sizes its LDS and the strides of B / w / pred for m_max; a setting whose m lies outside [1, m_max] (only a
+    direct caller of the C ABI can pass one) is not run: status (2, m), its neighbours' state untouched."""
+    import ctypes as C
+    import fmx
+    lib = fmx._lib.load()
+    dev = torch.device("cuda")
+    n, D, d, m_max = 64, 8, 8, 4
+    rng = np.random.default_rng(0)
+    X = torch.from_numpy(rng.normal(size=(n, D))).to(dev)
+    y = torch.from_numpy(np.sign(rng.normal(size=n))).to(dev)
+    ms = torch.tensor([4, 9, 2, 0], dtype=torch.int32, device=dev)                       # settings 1 and 3 are out of range
+    etas = torch.full((4,), 0.1, dtype=torch.float64, device=dev)
+    BP = torch.zeros((4, d * 2 * m_max), dtype=torch.float64, device=dev)
+    BN = torch.zeros_like(BP)
+    counts = torch.zeros((4, 2), dtype=torch.int32, device=dev)
+    pred = torch.full((4, n), 7.0, dtype=torch.float64, device=dev)
+    status = torch.zeros((4, 2), dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = lib.fmx_sftrl_grid(p(X), p(y), n, D, d, 4, p(ms), p(etas), m_max, 1e-12, 0, p(BP), p(BN), p(counts), None, None, p(pred), p(status),
+                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.fmx_last_error_string()
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert st[0, 0] == 0 and st[2, 0] == 0
+    assert tuple(st[1]) == (2, 9) and tuple(st[3]) == (2, 0)
+    pr = pred.cpu().numpy()
+    assert (pr[1] == 7.0).all() and (pr[3] == 7.0).all()                                 # nothing was run for them
+    assert (pr[0] != 7.0).any() and (pr[2] != 7.0).any()
+    assert float(BP[1].abs().sum()) == 0.0 and float(BP[3].abs().sum()) == 0.0
