@@ -697,10 +697,10 @@ def main():
         except Exception as exc:                            # the headline line must not be lost to the secondary workload
             out["secondary"] = {"deepfm": {"error": repr(exc)}}
         try:
-            # the HBM-resident companion: the vocabulary list scaled 16 x (fields capped at 2^20 - 1 rows): 15 M rows,
-            # 3.85 GB of FTRL rows -- 15 x the Infinity Cache -- and the Zipf(1.05) stream on the headline table
+            # the HBM-resident companion: the vocabulary list scaled 64 x (fields capped at 2^20 - 1 rows): 11.1 M rows,
+            # 2.84 GB of FTRL rows -- 11 x the Infinity Cache -- and the Zipf(1.05) stream on the headline table
             torch.cuda.empty_cache()
-            big = [min(s_ * 16, (1 << 20) - 1) for s_ in CRITEO_SIZES]
+            big = [min(s_ * 64, (1 << 20) - 1) for s_ in CRITEO_SIZES]
             out["secondary"]["fm_hbm_resident"] = fm_loop_probe(fmx, torch, dev, big, zipf=False)
             torch.cuda.empty_cache()
             out["secondary"]["fm_zipf"] = fm_loop_probe(fmx, torch, dev, CRITEO_SIZES, zipf=True)
