@@ -69,6 +69,8 @@ int nccl_fail(const char *what, ncclResult_t e) {
 
 }  // namespace
 
+int comm_destroy(Comm *c);
+
 int comm_unique_id(void *id_out) {
   Rccl *r = rccl();
   if (!r) return fail(FMX_ERR_UNSUPPORTED, "fmx_comm_unique_id: librccl.so.1 could not be loaded (%s)", dlerror());
@@ -101,7 +103,7 @@ int comm_create(const void *ids, int rank, int world, const int32_t *block_count
     ok = hipEventCreateWithFlags(&c->ready[s], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->free_[s], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
-    delete c;
+    (void)comm_destroy(c);
     return fail(FMX_ERR_LAUNCH, "fmx_comm_create: stream / event creation failed");
   }
   if (r) {
@@ -110,12 +112,12 @@ int comm_create(const void *ids, int rank, int world, const int32_t *block_count
     ncclComm_t a = nullptr, b = nullptr;
     ncclResult_t e = r->CommInitRank(&a, world, id[0], rank);
     if (e == ncclSuccess) e = r->CommInitRank(&b, world, id[1], rank);
+    c->main = a;  // (comm_destroy below releases whichever of the two exists, with the stream and the events)
+    c->pf = b;
     if (e != ncclSuccess) {
-      delete c;
+      (void)comm_destroy(c);
       return nccl_fail("ncclCommInitRank", e);
     }
-    c->main = a;
-    c->pf = b;
   }
   *out = c;
   return FMX_OK;

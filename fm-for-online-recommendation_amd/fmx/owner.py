@@ -216,10 +216,17 @@ class NativeOwnerFM:
         self._pref, self._next_slot = {}, 0
         self._bufs = None
 
-    def __del__(self):
+    def close(self):
+        """Release the communicator (its RCCL communicators, its stream and events); the caller has synchronised."""
         comm, self.comm = getattr(self, "comm", None), None
         if comm:
             self.lib.fmx_comm_destroy(comm)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown: the library or the runtime may already be gone
+            pass
 
     def _slot(self, slot, B):
         """The slot's buffers for a global batch of world x B samples, and its pre-bound call arguments (a call is then one
