@@ -639,6 +639,18 @@ template <> struct CoefA<false> {
   __device__ __forceinline__ CoefA up(int d) const { return {__shfl_up(v, d)}; }
 };
 
+#ifdef FMX_STAMPS  // diagnostic build (tools/update_stamps.sh): s_memrealtime (100 MHz) of every tile wave of the LAST k_fm_update launch
+__device__ unsigned long long g_upd_stamps[8192 * 6];
+#define FMX_STAMP(slot_, dep_)                                                                                      \
+  do {                                                                                                              \
+    unsigned long long t_;                                                                                          \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep_) : "memory");                      \
+    if (lane == 0 && gt < 8192) g_upd_stamps[(size_t)gt * 6 + (slot_)] = t_;                                         \
+  } while (0)
+#else
+#define FMX_STAMP(slot_, dep_) do {} while (0)
+#endif
+
 // One wave per tile of 64 sorted occurrences of one field.  Lane group s (LPR lanes; lane q owns coordinates 4q..4q+3)
 // walks EPG = 64 / SLOTS CONSECUTIVE occurrences sequentially, so duplicates inside a group are summed in registers;
 // one segmented scan over the SLOTS groups (log2(SLOTS) steps of wave shuffles) carries the sums of runs that span
@@ -667,6 +679,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   const int bbits = a.bbits;
   const uint32_t bmask = (1u << bbits) - 1u;
   const int e0 = base + slot * EPG;
+  FMX_STAMP(0, lane);
 
   uint32_t c[EPG];
   if constexpr (EPG % 4 == 0) {  // 16-byte loads (e0 is a multiple of EPG)
@@ -697,6 +710,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   }
 #pragma unroll
   for (int j = 0; j < EPG; ++j) tail[j] = val[j] && (k[j] != (j + 1 < EPG ? k[j + 1] : knext));
+  FMX_STAMP(1, k[0] + knext + kprev + tile_prevkey);  // the sorted list has arrived
 
   // ---- issue the loads: rows of the runs that end here (HBM / MALL), then S of every occurrence (L2) ----
   // Branch-free: an occurrence that is not the tail of a run starting in this tile requests the field's FIRST row instead
@@ -734,24 +748,43 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
     const float *xsrc = has_x ? a.xv : a.dz_first;  // something loadable
     const int fld = (has_x && a.cols) ? a.cols[f] : f;
     const int col = (has_x && a.fcols) ? a.fcols[fld] : fld;
-    const float *bisrc = a.dz_bi ? a.dz_bi : a.dz_first;
     float4 S4[EPG], G4[EPG];
     float xl[EPG], dzf[EPG], dzbl[EPG];
+    uint32_t bj[EPG];
+#pragma unroll
+    for (int j = 0; j < EPG; ++j) bj[j] = val[j] ? (c[j] & bmask) : 0u;
+    // What the common callers do not need is not requested: feature values when there are none, and the bi-interaction's
+    // coefficient when it is the first-order one (pure FM, DeepFM: dz_bi == dz_first; NFM: none).  Wave-uniform branches AHEAD
+    // of the other requests: the wait the compiler puts at their joins covers nothing else.  (No measurable change of the
+    // launch: the 2.5 us between the list's arrival and the arrival of S / dlogit / rows -- in-kernel stamps,
+    // tools/update_stamps.sh -- are the ~110 K distinct row lines of a step at the chip's ~54 G random lines per second.)
+    const bool sep_dzbi = a.dz_bi != nullptr && a.dz_bi != a.dz_first;
 #pragma unroll
     for (int j = 0; j < EPG; ++j) {
-      const uint32_t b = val[j] ? (c[j] & bmask) : 0u;
+      xl[j] = 1.f;
+      dzbl[j] = 0.f;
+    }
+    if (has_x) {
+#pragma unroll
+      for (int j = 0; j < EPG; ++j) xl[j] = xsrc[(size_t)bj[j] * a.Fx + col];
+    }
+    if (sep_dzbi) {
+#pragma unroll
+      for (int j = 0; j < EPG; ++j) dzbl[j] = a.dz_bi[(size_t)bj[j] * a.ld1];
+    }
+#pragma unroll
+    for (int j = 0; j < EPG; ++j) {
+      const uint32_t b = bj[j];
       S4[j] = *reinterpret_cast<const float4 *>(a.S + (size_t)b * a.ldS + 4 * q);
-      xl[j] = xsrc[has_x ? (size_t)b * a.Fx + col : (size_t)0];
       dzf[j] = a.dz_first[(size_t)b * a.ld1];
-      dzbl[j] = bisrc[(size_t)b * a.ld1];
       if constexpr (HAS_GBI) G4[j] = *reinterpret_cast<const float4 *>(a.gbi + (size_t)b * a.ldG + 4 * q);
       else G4[j] = splat(0.f);
     }
     if (!tile_open_early) request_rows();
 #pragma unroll
     for (int j = 0; j < EPG; ++j) {
-      const float x = has_x ? xl[j] : 1.f;
-      const float dzb = a.dz_bi ? dzbl[j] : 0.f;
+      const float x = xl[j];
+      const float dzb = a.dz_bi ? (sep_dzbi ? dzbl[j] : dzf[j]) : 0.f;
       const float w1 = x * dzf[j];
       float4 v;
       CA ca;
@@ -851,6 +884,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
   }
   if (INL) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FMX_STAMP(2, lane);  // every load issued so far (S / dlogit, the rows unless the tile publishes first) has arrived
     if (lane == 0)
       __hip_atomic_store(a.meta + (size_t)gt * 2, (int32_t)((a.seq << 4) | ((uint32_t)lead_state << 2) | (uint32_t)trail_state),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -893,6 +927,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
       }
     }
   }
+  FMX_STAMP(3, lane);  // pass 2 done: the row updates of the runs inside the tile are issued
   if (!INL) return;
   // ---- in-launch hand-off (INL): the CLOSING tile of a run sums the records of the tiles before it (they were
   //      dispatched earlier and wait on nothing) and applies the row update -- no second launch ----
@@ -960,6 +995,7 @@ __device__ __forceinline__ void update_body(const UpdArgs &a, const int blk) {
     aw += __shfl_xor(aw, mm);
   }
   if (lane < LPR) update_row<LAYOUT, RULE>(rp, q, kp, a.zoff, r, aV, aA, aw, a.h);
+  FMX_STAMP(4, lane);  // a closing tile: the crossing run's row is updated
 }
 
 template <int LPR, int LAYOUT, int RULE, bool HAS_GBI, bool INL>
@@ -2844,6 +2880,12 @@ int fmx_gather_read(const void *buf, int64_t bytes, int32_t row_bytes, int64_t n
   else hipLaunchKernelGGL((k_gather_read<8>), grid, block, 0, st, static_cast<const float4 *>(buf), n_rows, n_rows_read, seed, sink);
   return check_launch("k_gather_read");
 }
+
+#ifdef FMX_STAMPS
+int fmx_debug_update_stamps(unsigned long long *host_out) {  // [8192][6]; diagnostic build only (not in include/fmx.h)
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_upd_stamps), sizeof(unsigned long long) * 8192 * 6) == hipSuccess ? FMX_OK : FMX_ERR_LAUNCH;
+}
+#endif
 
 int fmx_stream_read(const void *buf, int64_t bytes, float *sink, fmx_stream_t stream) {
   if (!buf || !sink || bytes < 16 || bytes % 16) return fail(FMX_ERR_ARG, "fmx_stream_read: bad buffer");
