@@ -250,13 +250,7 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     c.loss_kind = loss_kind;
     c.inv_b = inv_b;
     c.stamps = tune().mlp_chain == 2 ? reinterpret_cast<unsigned long long *>(w.loss_lb) : nullptr;  // debug: tools/mlp_chain_stamps.py
-    static bool raised = false;
-    if (!raised) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)chain_lds_bytes(CH_MAXH));
-      raised = true;
-    }
-    hipLaunchKernelGGL(k_mlp_chain, dim3((B + CH_R - 1) / CH_R), dim3(256 + CH_LT), chain_lds_bytes(H), st, c);
+    hipLaunchKernelGGL(k_mlp_chain, dim3((B + CH_R - 1) / CH_R), dim3(256), chain_lds_bytes(H), st, c);
     mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st, true);
     return check_launch("fmx_mlp_section (k_mlp_chain)");
   }
