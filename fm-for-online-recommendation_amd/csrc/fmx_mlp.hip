@@ -98,12 +98,36 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
     g.ldmask = 0;
     g.c_split_stride = 0;
     g.zero_cols_to = 0;
+    g.stamps = nullptr;
     return g;
   };
   int splits[MLP_BIG_MAX_L] = {0};
   WgradBatch wb;
   wb.n = 0;
   int wgx = 1;
+  // the streaming weight-gradient kernel (k_mlp_wgrad_stream): 16-byte loads of dH_l (and of H_{l-1} where the layer is at
+  // least 64 wide), one split count for every layer chosen so that the 64 x 64 blocks of the wide layers fill the chip once
+  WgradStream sb;
+  sb.n = 0;
+  sb.per = 1;
+  bool stream = H % 4 == 0 && aligned16(w.dH) && aligned16(w.acts) && (size_t)B * H * 4 < 0x7FFFFF00ull;
+  int stream_splits = 1;
+  {
+    int heavy = 0;
+    for (int l = 0; l < L; ++l) {
+      const int in = l == 0 ? k : H;
+      if (in % 4 != 0 || (in < 64 && in > 48)) stream = false;
+      if (l == 0 && in >= 64 && (ld_bi % 4 != 0 || !aligned16(bi))) stream = false;
+      if (in >= 64) heavy += ((H + 63) / 64) * ((in + 63) / 64);
+    }
+    if (heavy < 1) heavy = 1;
+    stream_splits = 256 / heavy;
+    if (stream_splits > w.n_split) stream_splits = w.n_split;
+    if (stream_splits < 1) stream_splits = 1;
+    sb.rows_per_split = ((B + stream_splits - 1) / stream_splits + 15) / 16 * 16;
+    stream_splits = (B + sb.rows_per_split - 1) / sb.rows_per_split;
+    sb.B = B;
+  }
   for (int l = L - 1; l >= 0; --l) {
     const int in = l == 0 ? k : H;
     float *cur = w.dH + (size_t)l * act;
@@ -132,6 +156,24 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
       g.a_bytes = (unsigned)((size_t)B * g.lda * 4);
       g.b_bytes = (unsigned)((size_t)B * g.ldb * 4);
       g.vec = (size_t)B * (g.lda > g.ldb ? g.lda : g.ldb) * 4 < 0xFFFFFF00ull && gemm_vec_ok(g, 1, 0);
+      if (stream) {
+        WgradLayer &sl = sb.g[sb.n];
+        sl.dH = cur;
+        sl.Hp = prev;
+        sl.P = w.parts[l];
+        sl.split_stride = (long long)H * w.ldp[l];
+        sl.M = H;
+        sl.N = in;
+        sl.lda = H;
+        sl.ldb = ldprev;
+        sl.ldp = w.ldp[l];
+        sl.tiles_m = (H + 63) / 64;
+        sl.tiles_n = in >= 64 ? (in + 63) / 64 : 1;
+        sb.z_end[sb.n] = (sb.n ? sb.z_end[sb.n - 1] : 0) + stream_splits;
+        if (sl.tiles_m * sl.tiles_n > sb.per) sb.per = sl.tiles_m * sl.tiles_n;
+        ++sb.n;
+        splits[l] = stream_splits;
+      }
       wb.g[wb.n] = g;                                  // launched together with the other layers' after the dgrad chain
       wb.z_end[wb.n] = (wb.n ? wb.z_end[wb.n - 1] : 0) + n_split;
       wb.bias_col[wb.n] = in;
@@ -166,16 +208,26 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
       launch_gemm<0, 0, EPI_NONE>(g, 1, st);
     }
   }
-  {  // ---- every layer's dW_l | db_l in one launch ----
+  if (stream) {  // ---- every layer's dW_l | db_l in one launch, operands streamed into registers ----
+    static bool raised_s = false;
+    if (!raised_s) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_wgrad_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES);
+      raised_s = true;
+    }
+    const int zs = sb.z_end[sb.n - 1];
+    hipLaunchKernelGGL(k_mlp_wgrad_stream, dim3(8 * ((zs + 7) / 8) * sb.per), dim3(256), WS_LDS_BYTES, st, sb);
+  } else {  // ---- the same as 64 x 64 x 32 tiles staged through LDS (any shape) ----
     static bool raised = false;
     if (!raised) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)g_lds_bytes(G_BK_WGRAD));
       raised = true;
     }
-    // grid x = the GEMM's column tiles + one slice for the bias columns (y there = blocks of 64 columns of dH_l)
-    hipLaunchKernelGGL(k_mlp_wgrad, dim3(wgx + 1, (H + G_BM - 1) / G_BM, wb.z_end[wb.n - 1]), dim3(256), g_lds_bytes(G_BK_WGRAD), st,
-                       wb);
+    wb.tx = wgx;
+    wb.stamps = tune().mlp_chain == 3 ? reinterpret_cast<unsigned long long *>(w.dzl) : nullptr;  // debug: tools/mlp_wgrad_stamps.py
+    wb.ty = (H + G_BM - 1) / G_BM;
+    const int per = wb.tx * wb.ty + wb.ty, zs = wb.z_end[wb.n - 1];
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3(8 * ((zs + 7) / 8) * per), dim3(256), g_lds_bytes(G_BK_WGRAD), st, wb);
   }
   MlpReduceArgs a;
   long long biggest = 0;
