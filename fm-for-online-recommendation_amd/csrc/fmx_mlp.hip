@@ -124,10 +124,13 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
     stream_splits = 256 / heavy;
     if (stream_splits > w.n_split) stream_splits = w.n_split;
     if (stream_splits < 1) stream_splits = 1;
-    sb.rows_per_split = ((B + stream_splits - 1) / stream_splits + 15) / 16 * 16;
-    stream_splits = (B + sb.rows_per_split - 1) / sb.rows_per_split;
     sb.B = B;
   }
+  auto stream_rows = [&](int in) {  // rows per split: the narrow layers (a quarter of the MFMAs per step) in four times the splits
+    int ns = in >= 64 ? stream_splits : 2 * stream_splits;
+    if (ns > w.n_split) ns = w.n_split;
+    return ((B + ns - 1) / ns + 15) / 16 * 16;
+  };
   for (int l = L - 1; l >= 0; --l) {
     const int in = l == 0 ? k : H;
     float *cur = w.dH + (size_t)l * act;
@@ -169,10 +172,11 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
         sl.ldp = w.ldp[l];
         sl.tiles_m = (H + 63) / 64;
         sl.tiles_n = in >= 64 ? (in + 63) / 64 : 1;
-        sb.z_end[sb.n] = (sb.n ? sb.z_end[sb.n - 1] : 0) + stream_splits;
+        sl.rows_per_split = stream_rows(in);
+        splits[l] = (B + sl.rows_per_split - 1) / sl.rows_per_split;
+        sb.z_end[sb.n] = (sb.n ? sb.z_end[sb.n - 1] : 0) + splits[l];
         if (sl.tiles_m * sl.tiles_n > sb.per) sb.per = sl.tiles_m * sl.tiles_n;
         ++sb.n;
-        splits[l] = stream_splits;
       }
       wb.g[wb.n] = g;                                  // launched together with the other layers' after the dgrad chain
       wb.z_end[wb.n] = (wb.n ? wb.z_end[wb.n - 1] : 0) + n_split;
@@ -215,6 +219,7 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
       raised_s = true;
     }
     const int zs = sb.z_end[sb.n - 1];
+    sb.stamps = tune().mlp_chain == 3 ? reinterpret_cast<unsigned long long *>(w.dzl) : nullptr;  // debug: tools/mlp_wgrad_stamps.py
     hipLaunchKernelGGL(k_mlp_wgrad_stream, dim3(8 * ((zs + 7) / 8) * sb.per), dim3(256), WS_LDS_BYTES, st, sb);
   } else {  // ---- the same as 64 x 64 x 32 tiles staged through LDS (any shape) ----
     static bool raised = false;

@@ -21,19 +21,23 @@ for _ in range(5):
 torch.cuda.synchronize()
 al = lambda x: (x + 255) // 256 * 256
 off = 2 * L * al(B * H * 4) + al(B * 4)          # bytes: acts, dH, loss_b -> dzl
-n_wg = 1280
+n_wg = 768
 s = ws.view(torch.uint8)[off:off + n_wg * 8 * 8].cpu().numpy().view(np.uint64).reshape(n_wg, 8).astype(np.int64)
 live = s[:, 0] > 0
-heavy = live & (s[:, 4] > 0)        # eight tiles: the 256 x 256 layers
 t0 = s[live, 0].min()
-print("workgroups with a GEMM tile: %d (of them with >= 4 tiles: %d); start spread %.2f us; last end %.2f us" %
-      (live.sum(), heavy.sum(), (s[live, 0].max() - t0) / 100.0, (s[live, 6].max() - t0) / 100.0))
+dur = (s[:, 4] - s[:, 0]) / 100.0
+heavy = live & (dur > np.median(dur[live]) * 0.6)
+print("workgroups: %d live, %d heavy; start spread %.2f us; last end %.2f us" % (live.sum(), heavy.sum(), (s[live, 0].max() - t0) / 100.0, (s[live, 4].max() - t0) / 100.0))
 h = s[heavy]
-names = ["start -> first tile staged", "tile 0", "tile 1", "tiles 2-3", "tiles 4-7", "epilogue"]
-for i in range(1, 7):
+names = ["start -> first 8 steps done", "the other steps", "LDS hand-over + barrier", "sum + stores"]
+for i in range(1, 5):
     d = (h[:, i] - h[:, i - 1]) / 100.0
-    print("%-28s median %.2f us  p10 %.2f  p90 %.2f" % (names[i - 1], np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
-print("heavy workgroup, start -> end: median %.2f us; starts (from the first): p10 %.2f p50 %.2f p90 %.2f max %.2f" %
-      (np.median(h[:, 6] - h[:, 0]) / 100.0, *[np.percentile(h[:, 0] - t0, q) / 100.0 for q in (10, 50, 90, 100)]))
-ids = np.nonzero(live)[0]
-print("XCC id of workgroup i vs i % 8 (first 16):", [(int(i) % 8, int(s[i, 7])) for i in ids[:16]])
+    print("%-28s median %.2f us  p10 %.2f  p90 %.2f  max %.2f" % (names[i - 1], np.median(d), np.percentile(d, 10), np.percentile(d, 90), d.max()))
+print("heavy workgroup, start -> end: median %.2f us, max %.2f; light: median %.2f" % (np.median(dur[heavy]), dur[heavy].max(), np.median(dur[live & ~heavy]) if (live & ~heavy).any() else 0))
+hw = s[:, 7] >> 8
+cu = ((s[:, 7] & 0xF) << 8) | (((hw >> 13) & 0x7) << 4) | ((hw >> 8) & 0xF)     # (XCC, SE, CU)
+import collections
+cnt = collections.Counter(cu[heavy].tolist())
+print("heavy workgroups per CU: %s over %d CUs" % (dict(collections.Counter(cnt.values())), len(cnt)))
+cnt2 = collections.Counter(cu[live].tolist())
+print("all workgroups per CU: %s over %d CUs" % (dict(collections.Counter(cnt2.values())), len(cnt2)))
