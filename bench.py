@@ -219,8 +219,20 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
             dist.barrier()
             torch.cuda.synchronize()
 
+    # one GPU: the steps of the pool issued from ONE foreign call (fmx_deepfm_stream) -- through the Python trainer the step is bound
+    # by its host side (84 us of calls per step for 67 us of kernels); that path is timed beside it as `through_trainer_step`
+    native_loop = None
+    if world == 1 and not owners and getattr(tr, "native", False) and os.environ.get("FMX_DEEPFM_STREAM", "1") == "1":
+        work = torch.cuda.Stream(device=dev)
+        loop_losses = torch.zeros(max(min(args.steps, 100), 10), device=dev)
+        native_loop = tr.prepare_stream(idx_pool, y_pool, loss_out=loop_losses, stream=work)
+        torch.cuda.synchronize()                              # the tables and the pool were written on torch's current stream
+
     def run(n, first=0):
         out = None
+        if native_loop is not None:
+            native_loop(n)
+            return loop_losses[n - 1]
         if owners:                                            # the index all-gather and the sort of the owned pieces run two steps ahead
             tokens = {d: tr.prefetch(idx_pool[(first + d) % N_POOL]) for d in range(min(2, n))}
             for s in range(n):
@@ -242,6 +254,15 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
     dt = time.perf_counter() - t0
     eng.check_error_flag()
     loss = last.clone()
+    through_trainer = None
+    if native_loop is not None:                               # the same steps through DeepFMTrainer.step, for the record
+        native_loop = None
+        run(warm)
+        barrier()
+        t1 = time.perf_counter()
+        run(steps, warm)
+        barrier()
+        through_trainer = steps * BATCH / (time.perf_counter() - t1)
     if world > 1:
         tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -271,7 +292,9 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
         "mlp_section": {"flop_per_step": flops, "note": "3 x (forward + dgrad + wgrad) fp32-MFMA GEMMs; TFLOP/s over the WHOLE step "
                         "(tables included) is a lower bound of the section's rate", "TFLOPs_whole_step": flops / (dt / steps) / 1e12,
                         "frac_of_fp32_mfma_peak_whole_step": flops / (dt / steps) / 1e12 / 157.3},
-        "final_loss": float(loss)})
+        "final_loss": float(loss),
+        **({"issued_by": "fmx_deepfm_stream: one foreign call for the timed steps", "through_trainer_step_samples_per_s": through_trainer}
+           if through_trainer is not None else {})})
 
 
 PUBLISHED_ONLINE = {"FMAdam": 39.1, "NFMAdam": 35.9, "NFMOnn": 27.9, "DeepFMAdam": 27.4, "DeepFMOnn": 18.4}

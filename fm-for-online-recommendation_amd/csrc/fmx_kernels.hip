@@ -2366,6 +2366,93 @@ int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
                      static_cast<hipStream_t>(stream), nullptr, sample_ld);
 }
 
+// The mini-batch DeepFM loop over a device-resident pool (BASELINE configs[3]): per step the forward of the tables, the MLP
+// section on bi (fmx_mlp_section: k_mlp_chain, k_mlp_wgrad_stream, k_mlp_reduce with the SGD of the MLP applied in it) and the
+// table update with dL/dbi, all issued from here; the occurrence sorts run in groups on the side stream as in fmx_fm_stream.
+// Through the Python trainer the same step is bound by its host side (84 us of calls per step for 67 us of kernels).
+int fmx_deepfm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const fmx_mlp_t *mlp, int32_t loss_kind,
+                      const int32_t *idx_pool, const float *y_pool, int32_t n_pool, int32_t B, float inv_b, int32_t n_steps,
+                      void *workspace, int64_t workspace_bytes, void *mlp_workspace, const fmx_fwd_out_t *fwd, float *dz, float *gbi,
+                      float *grads, float lr_mlp, float *loss_out, fmx_stream_t stream) {
+  if (int rc = check_table(table)) return rc;
+  if (int rc = check_rule(table, rule)) return rc;
+  if (!hyper || !mlp || !workspace || !mlp_workspace || !fwd || !fwd->S || !fwd->bi || !fwd->logit || !dz || !gbi || !grads)
+    return fail(FMX_ERR_ARG, "fmx_deepfm_stream: null argument (fwd needs S, bi and logit)");
+  if (fwd->sample_ld != 0) return fail(FMX_ERR_ARG, "fmx_deepfm_stream: dense forward outputs only (sample_ld = 0)");
+  if (!idx_pool || !y_pool || n_pool < 1 || n_steps < 0 || B < 1) return fail(FMX_ERR_ARG, "fmx_deepfm_stream: bad pool / step count");
+  if (mlp->k > table->kp) return fail(FMX_ERR_SHAPE, "fmx_deepfm_stream: the MLP reads k=%d columns of a bi of kp=%d", mlp->k, table->kp);
+  if (!aligned16(gbi) || !aligned16(dz)) return fail(FMX_ERR_ALIGN, "dz and gbi must be 16-byte aligned");
+  if (int rc = check_sort_geometry(table, B)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = check_workspace(table, B, workspace, workspace_bytes, "fmx_deepfm_stream")) return rc;
+  const Workspace w = carve(table, B, workspace);
+  const size_t F = (size_t)n_cols(table);
+  int rc = FMX_OK;
+  Side *sd = (B >= OVERLAP_MIN_BATCH && n_steps > 0) ? side_for_current_device() : nullptr;
+  hipStream_t user = st;
+  const bool detour = sd && st == nullptr;  // off the legacy default stream (see fmx_fm_stream)
+  if (detour) {
+    (void)hipEventRecord(sd->user_fork, user);
+    st = sd->main;
+    (void)hipStreamWaitEvent(st, sd->user_fork, 0);
+  }
+  int ahead = tune().sort_ahead;
+  if (ahead < 1) ahead = 1;
+  if (ahead > SORT_AHEAD_MAX) ahead = SORT_AHEAD_MAX;
+  auto group_size = [&](int g, int first_step) {
+    int n = g == 0 ? 4 : ahead;
+    if (n > ahead) n = ahead;
+    if (n > n_steps - first_step) n = n_steps - first_step;
+    return n;
+  };
+  auto sort_group = [&](int g, int first_step, int n, hipStream_t where) -> int {
+    SortBatch mb;
+    mb.n_pool = n_pool;
+    mb.first = first_step % n_pool;
+    mb.n_batches = n;
+    mb.pool_stride = (int64_t)B * (int64_t)F;
+    mb.sorted_stride = (int64_t)w.sorted_stride;
+    return sort_impl(table, idx_pool, B, w.sorted + (size_t)(g & 1) * ahead * w.sorted_stride, w.runs, fwd->error, where, &mb);
+  };
+  if (sd && n_steps > 0) {
+    (void)hipEventRecord(sd->fork, st);
+    (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
+    rc = sort_group(0, 0, group_size(0, 0), sd->stream);
+    (void)hipEventRecord(sd->sorted[0], sd->stream);
+  }
+  int first_step = 0;
+  for (int g = 0; first_step < n_steps && rc == FMX_OK; ++g) {
+    const int n = group_size(g, first_step);
+    const int next_first = first_step + n;
+    if (!sd) rc = sort_group(g, first_step, n, st);
+    for (int i = 0; i < n && rc == FMX_OK; ++i) {
+      const int s = first_step + i, j = s % n_pool;
+      const int32_t *idx = idx_pool + (size_t)j * B * F;
+      const float *y = y_pool + (size_t)j * B;
+      const uint32_t *sorted = w.sorted + ((size_t)(g & 1) * ahead + i) * w.sorted_stride;
+      rc = forward_impl(table, hyper, idx, nullptr, nullptr, B, FMX_LOSS_NONE, inv_b, fwd, st);
+      if (rc == FMX_OK)
+        rc = fmx_mlp_section(mlp, loss_kind, fwd->bi, table->kp, fwd->logit, y, B, inv_b, mlp_workspace, nullptr, dz, gbi, table->kp, grads,
+                             lr_mlp, loss_out ? loss_out + s : nullptr, st);
+      if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
+      if (rc == FMX_OK)
+        rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, dz, dz, gbi, B, nullptr, inv_b, nullptr, st, nullptr, 0, fwd->error);
+      if (sd && i == 0 && next_first < n_steps && rc == FMX_OK) {
+        if (g >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[(g + 1) & 1], 0);
+        rc = sort_group(g + 1, next_first, group_size(g + 1, next_first), sd->stream);
+        (void)hipEventRecord(sd->sorted[(g + 1) & 1], sd->stream);
+      }
+    }
+    if (sd) (void)hipEventRecord(sd->consumed[g & 1], st);
+    first_step = next_first;
+  }
+  if (detour) {
+    (void)hipEventRecord(sd->user_join, st);
+    (void)hipStreamWaitEvent(user, sd->user_join, 0);
+  }
+  return rc;
+}
+
 // ---- the field-owner step with the library's own communicator (fmx_comm.hip) ----
 static int owner_geometry(const Comm *c, const fmx_table_t *table, int32_t B, int32_t slot, int &GB, const char *who) {
   if (!c) return fail(FMX_ERR_ARG, "%s: null communicator", who);

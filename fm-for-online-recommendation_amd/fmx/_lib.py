@@ -17,7 +17,7 @@ LOSSES = {None: LOSS_NONE, "none": LOSS_NONE, "logits": LOSS_BCE_LOGITS, "sigmoi
 EXPORTS = ["fmx_version", "fmx_last_error_string", "fmx_set_option", "fmx_sorted_width", "fmx_sorted_bbits", "fmx_workspace_bytes",
            "fmx_fm_forward", "fmx_mlp_forward", "fmx_mlp_fit", "fmx_mlp_hedge_fit", "fmx_mlp_section",
            "fmx_mlp_section_workspace_bytes", "fmx_fm_online_run", "fmx_online_run_mlp", "fmx_mlp_forward_batch", "fmx_mlp_hedge_section",
-           "fmx_sort_occurrences", "fmx_fm_update", "fmx_fm_step", "fmx_fm_stream", "fmx_stream_read",
+           "fmx_sort_occurrences", "fmx_fm_update", "fmx_fm_step", "fmx_fm_stream", "fmx_deepfm_stream", "fmx_stream_read",
            "fmx_fm_forward_partial", "fmx_fm_forward_finish", "fmx_sftrl_run", "fmx_sftrl_grid",
            "fmx_gather_read", "fmx_comm_unique_id", "fmx_comm_create", "fmx_comm_destroy", "fmx_owner_prefetch", "fmx_owner_step"]
 
@@ -108,6 +108,7 @@ def load():
     lib.fmx_mlp_section_workspace_bytes.restype = C.c_int64
     lib.fmx_mlp_section_workspace_bytes.argtypes = [MP, i32]
     lib.fmx_mlp_section.argtypes = [MP, i32, p, i32, p, p, i32, f32, p, p, p, p, i32, p, f32, p, p]
+    lib.fmx_deepfm_stream.argtypes = [TP, HP, i32, MP, i32, p, p, i32, i32, f32, i32, p, i64, p, FP, p, p, p, f32, p, p]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name in I64_RETURNS:

@@ -218,6 +218,34 @@ class FMEngine:
         run.keep = keep
         return run
 
+    def prepare_deepfm_stream(self, hyper, rule, loss, params, grads, k, hidden, n_layers, lr_mlp, idx_pool, y_pool, loss_out=None,
+                              stream=None):
+        """-> run(n_steps): the mini-batch DeepFM loop over a resident pool (fmx_deepfm_stream), every argument but the step count
+        bound once; per step forward, MLP section (SGD of the MLP applied in it: lr_mlp), table update, all issued from one call.
+        `params` / `grads`: the flat MLP buffers (W_l then b_l per layer).  The caller keeps the tensors alive and does not grow
+        the engine between prepare and run."""
+        n_pool, B, F = idx_pool.shape
+        assert F == self.table.n_fields and y_pool.shape == (n_pool, B)
+        assert loss_out is None or loss_out.is_contiguous()
+        self._ensure(B)
+        out = self._fwd_out(want_first=False, want_bi=True)
+        m = self._mlp_struct(params, k, hidden, n_layers)
+        self._mlp_big_buffers(m, k, hidden, n_layers, B)
+        fn, check = self.lib.fmx_deepfm_stream, _lib.check
+        fixed = (self.table.c_struct(), hyper.ref(), _lib.RULES[rule], C.byref(m), _lib.LOSSES[loss], idx_pool.data_ptr(), y_pool.data_ptr(),
+                 n_pool, B, 1.0 / B)
+        tail = (self.workspace.data_ptr(), self._ws_bytes(), self._mlp_ws.data_ptr(), C.byref(out), self._mlp_dz.data_ptr(),
+                self._mlp_gbi.data_ptr(), grads.data_ptr(), lr_mlp, _ptr(loss_out), self._stream(stream))
+        cap = None if loss_out is None else loss_out.numel()
+        keep = (out, m, hyper, params, grads, idx_pool, y_pool, loss_out, self.workspace, self._mlp_ws, self._mlp_dz, self._mlp_gbi)
+
+        def run(n_steps):
+            if cap is not None and n_steps > cap:
+                raise ValueError(f"loss_out holds {cap} steps, {n_steps} asked for")
+            check(fn(*fixed, n_steps, *tail))
+        run.keep = keep
+        return run
+
     # ---- the small fused MLP (online steps of DeepFM / NFM / ONN); shapes beyond its limits raise FmxError(UNSUPPORTED) ----
     MLP_MAX_B, MLP_MAX_W, MLP_MAX_L = 16, 64, 8
 

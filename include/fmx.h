@@ -50,8 +50,8 @@
 extern "C" {
 #endif
 
-#define FMX_VERSION 103 /* 0.1.3: fields as row-range pieces of index columns (field_cols / field_base / n_cols), workspace_bytes arguments,
-                           fmx_owner_* */
+#define FMX_VERSION 104 /* 0.1.4: fmx_deepfm_stream (0.1.3: fields as row-range pieces of index columns -- field_cols / field_base /
+                           n_cols --, workspace_bytes arguments, fmx_owner_*) */
 
 typedef void *fmx_stream_t; /* hipStream_t */
 
@@ -372,6 +372,20 @@ int64_t fmx_mlp_section_workspace_bytes(const fmx_mlp_t *mlp, int32_t B);
 int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, int32_t ld_bi, const float *base,
                     const float *y, int32_t B, float inv_b, void *workspace, float *logit_out, float *dz_out,
                     float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply, float *loss_out, fmx_stream_t stream);
+
+/* The mini-batch DeepFM loop over a device-resident stream of mini-batches (BASELINE configs[3]): step s uses batch (s mod n_pool);
+ * per step the forward of the tables (S, bi, FM logit), fmx_mlp_section on bi with the FM logit as base (the SGD of the MLP applied in
+ * its reduction: lr_mlp), then the row-reduced table update with dz_first = dz_bi = dL/dlogit and gbi = dL/dbi -- the launches of a
+ * step issued back to back from one call, the occurrence sorts in groups on the library's side stream as in fmx_fm_stream.
+ * idx_pool [n_pool, B, F], y_pool [n_pool, B]; fwd: S, bi, logit (dense, sample_ld = 0); dz [B], gbi [B, kp], grads (layout of
+ * mlp->params) are scratch the call fills; loss_out [n_steps] or null; workspace: fmx_workspace_bytes(table, B), mlp_workspace:
+ * fmx_mlp_section_workspace_bytes(mlp, B).  The result is the one of calling fmx_fm_forward, fmx_mlp_section, fmx_sort_occurrences
+ * and fmx_fm_update per step.
+ * Replaces: the mini-batch driver loop over DeepFMAdam.fit (reference main_experiment.py:92-105 with deepfm_adam.py:106-119). */
+int fmx_deepfm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const fmx_mlp_t *mlp, int32_t loss_kind,
+                      const int32_t *idx_pool, const float *y_pool, int32_t n_pool, int32_t B, float inv_b, int32_t n_steps,
+                      void *workspace, int64_t workspace_bytes, void *mlp_workspace, const fmx_fwd_out_t *fwd, float *dz, float *gbi,
+                      float *grads, float lr_mlp, float *loss_out, fmx_stream_t stream);
 
 /* Hedge backprop at mini-batch sizes (the ONN classes' fit() beyond 16 samples; reference deepfm_onn.py:109-154): per
  * layer BCELoss(sigmoid(base + sum_j x_l[j]), y), hidden layers updated by lr * sum_{i >= j} alpha_i dloss_i/dlayer_j (one

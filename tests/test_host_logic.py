@@ -115,7 +115,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(fmx._lib.EXPORTS), declared ^ set(fmx._lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.fmx_version() == 103
+    assert lib.fmx_version() == 104
     assert (lib.fmx_sorted_width(1), lib.fmx_sorted_width(65), lib.fmx_sorted_width(4096)) == (64, 128, 4096)
     assert (lib.fmx_sorted_bbits(1), lib.fmx_sorted_bbits(4096), lib.fmx_sorted_bbits(4097)) == (6, 12, 13)
 

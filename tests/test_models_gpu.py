@@ -378,6 +378,45 @@ def test_deep_trainer_step_vs_oracle(name, native):
     assert_state_close(got, ref, {kk: sd0[kk] for kk in ref}, what=f"{name} sgd step")
 
 
+def test_deepfm_stream_equals_trainer_steps():
+    """fmx_deepfm_stream (DeepFMTrainer.prepare_stream: the steps of a pool of batches issued from one foreign call, the sorts in
+    groups on the side stream) against DeepFMTrainer.step on the same batches: tables, MLP parameters and per-step losses
+    identical bits.  B = 256 takes the side-stream path, 13 steps over a pool of 5 batches cross a sort group and wrap the pool;
+    the step path itself is pinned against the oracle by test_deep_trainer_step_vs_oracle."""
+    import fmx
+    import torch.nn as nn
+    sizes, k, H, L, B, n_pool, n_steps, lr = [50, 7, 300, 2, 1200, 33], 16, 256, 3, 256, 5, 13, 0.01
+    rng = np.random.default_rng(3)
+    idx = np.stack([np.stack([rng.integers(0, s, size=B) for s in sizes], axis=1) for _ in range(n_pool)]).astype(np.int32)
+    y = (rng.uniform(size=(n_pool, B)) < 0.4).astype(np.float32)
+    results = []
+    for mode in ("steps", "stream"):
+        torch.manual_seed(5)
+        table = fmx.FlatTable(sizes, k, layout="weights")
+        g = torch.Generator(device="cuda").manual_seed(9)
+        table.rows[:, :k + 1] = torch.randn((table.n_rows, k + 1), generator=g, device="cuda") * 0.1
+        eng = fmx.FMEngine(table, max_batch=B)
+        layers = [nn.Linear(k if j == 0 else H, H).cuda() for j in range(L)]
+        tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=lr), "sgd"), layers, k, table.kp, mlp_lr=lr)
+        assert tr.native
+        idx_d, y_d = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
+        losses = torch.zeros(n_steps, device="cuda")
+        if mode == "steps":
+            for s in range(n_steps):
+                losses[s] = tr.step(idx_d[s % n_pool], y_d[s % n_pool])
+        else:
+            run = tr.prepare_stream(idx_d, y_d, loss_out=losses)
+            run(4)                                    # two calls: the second starts in the middle of the pool
+            run2 = tr.prepare_stream(torch.roll(idx_d, -4, 0).contiguous(), torch.roll(y_d, -4, 0).contiguous(), loss_out=losses[4:])
+            run2(n_steps - 4)
+        torch.cuda.synchronize()
+        eng.check_error_flag()
+        results.append((table.rows.cpu().numpy().copy(), tr.flat.cpu().numpy().copy(), losses.cpu().numpy().copy()))
+    for a, b, what in zip(results[0], results[1], ("tables", "MLP parameters", "losses")):
+        assert np.array_equal(a, b), what
+    assert np.all(np.isfinite(results[0][2])) and results[0][2].std() > 0
+
+
 def test_deep_trainer_full_size_step_vs_oracle():
     """BASELINE configs[3] END TO END at its full size: one online DeepFM step (Criteo vocabulary R = 1,006,628, k = 16,
     3 x 256 relu MLP, B = 4096, SGD lr 1e-3) through fmx.DeepFMTrainer -- sort, forward, the MLP section (k_mlp_chain +
