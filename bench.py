@@ -713,7 +713,8 @@ def main():
             ns = argparse.Namespace(steps=100, warmup=10, zipf=False, mp_mode="owner")
             first = bench_deepfm(ns, fmx, torch, dist, 1, 0, dev, False)          # (pays the one-time set-up: workspaces, first launches)
             sec = bench_deepfm(ns, fmx, torch, dist, 1, 0, dev, False)
-            out["secondary"] = {"deepfm": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "mlp_section", "config")}}
+            out["secondary"] = {"deepfm": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "mlp_section", "config", "issued_by",
+                                                               "through_trainer_step_samples_per_s") if k in sec}}
             out["secondary"]["deepfm"]["passes"] = {"note": "two passes of 100 steps in this process; `value` is the SECOND (the first pays "
                                                     "one-time set-up); both are given", "first": first["value"], "second": sec["value"]}
             out["secondary"]["deepfm"]["roofline"] = mlp_section_probe(fmx, torch, dev)

@@ -24,9 +24,10 @@ def short(n):
 ks = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
 upd = [i for i, k in enumerate(ks) if k[0] == "k_fm_update"]
 import os
-skip = 120 if len(upd) > 300 else 0   # bench.py times the trainer's step after the native loop: look at the loop
-upd = upd[:len(upd) - skip] if skip else upd
-lo, hi = upd[-91], upd[-1]          # 90 steps: from the end of one update to the end of the last
+if len(upd) >= 220:                  # bench.py --workload deepfm: 10 + 100 steps of the native loop, then 10 + 100 through the trainer
+    lo, hi = upd[15], upd[105]
+else:
+    lo, hi = upd[-91], upd[-1]       # 90 steps: from the end of one update to the end of the last
 seg = ks[lo + 1:hi + 1]
 span = (ks[hi][2] - ks[lo][2]) / 90 / 1e3
 dur = collections.defaultdict(list)

@@ -9,17 +9,17 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU_M
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/${tag}_pmc_$name -o p -- python3 $root/tools/mlp_section_times.py > $out/${tag}_pmc_$name.log 2>&1 || echo "pass $grp failed"
   f=$(find $out/${tag}_pmc_$name -name "p_counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
-import csv, sys, collections
+import csv, sys, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 try:
     for r in csv.DictReader(open(sys.argv[1])):
-        n = r["Kernel_Name"]
-        if "k_mlp" not in n: continue
-        acc[n.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        m = re.search(r"(k_mlp_\w+)", r["Kernel_Name"])
+        if not m: continue
+        acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 except Exception as e:
     print("no counters:", e)
 for k, d in acc.items():
     for c, v in d.items():
-        print("%-42s %-30s launches %5d  mean %14.1f" % (k, c, len(v), sum(v) / len(v)))
+        print("%-20s %-30s launches %5d  mean %14.1f" % (k, c, len(v), sum(v) / len(v)))
 PY
 done
