@@ -2371,11 +2371,17 @@ int fmx_fm_update(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t ru
                      static_cast<hipStream_t>(stream), nullptr, sample_ld);
 }
 
+// NFM's input logit: the first-order sum plus the bias (reference nfm_adam.py:78-88), one fp32 add per sample as the trainer does it
+__global__ void k_first_plus_bias(float *out, const float *sfirst, const float *bias, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = sfirst[b] + bias[0];
+}
+
 // The mini-batch DeepFM loop over a device-resident pool (BASELINE configs[3]): per step the forward of the tables, the MLP
 // section on bi (fmx_mlp_section: k_mlp_chain, k_mlp_wgrad_stream, k_mlp_reduce with the SGD of the MLP applied in it) and the
 // table update with dL/dbi, all issued from here; the occurrence sorts run in groups on the side stream as in fmx_fm_stream.
 // Through the Python trainer the same step is bound by its host side (84 us of calls per step for 67 us of kernels).
-int fmx_deepfm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const fmx_mlp_t *mlp, int32_t loss_kind,
+int fmx_deepfm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const fmx_mlp_t *mlp, int32_t loss_kind, int32_t fm_term,
                       const int32_t *idx_pool, const float *y_pool, int32_t n_pool, int32_t B, float inv_b, int32_t n_steps,
                       void *workspace, int64_t workspace_bytes, void *mlp_workspace, const fmx_fwd_out_t *fwd, float *dz, float *gbi,
                       float *grads, float lr_mlp, float *loss_out, fmx_stream_t stream) {
@@ -2384,6 +2390,8 @@ int fmx_deepfm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_
   if (!hyper || !mlp || !workspace || !mlp_workspace || !fwd || !fwd->S || !fwd->bi || !fwd->logit || !dz || !gbi || !grads)
     return fail(FMX_ERR_ARG, "fmx_deepfm_stream: null argument (fwd needs S, bi and logit)");
   if (fwd->sample_ld != 0) return fail(FMX_ERR_ARG, "fmx_deepfm_stream: dense forward outputs only (sample_ld = 0)");
+  if (!fm_term && (!fwd->sfirst || table->layout != FMX_LAYOUT_WEIGHTS))
+    return fail(FMX_ERR_UNSUPPORTED, "fmx_deepfm_stream: fm_term = 0 (NFM) needs fwd->sfirst and a table in the weights layout");
   if (!idx_pool || !y_pool || n_pool < 1 || n_steps < 0 || B < 1) return fail(FMX_ERR_ARG, "fmx_deepfm_stream: bad pool / step count");
   if (mlp->k > table->kp) return fail(FMX_ERR_SHAPE, "fmx_deepfm_stream: the MLP reads k=%d columns of a bi of kp=%d", mlp->k, table->kp);
   if (!aligned16(gbi) || !aligned16(dz)) return fail(FMX_ERR_ALIGN, "dz and gbi must be 16-byte aligned");
@@ -2436,12 +2444,17 @@ int fmx_deepfm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_
       const float *y = y_pool + (size_t)j * B;
       const uint32_t *sorted = w.sorted + ((size_t)(g & 1) * ahead + i) * w.sorted_stride;
       rc = forward_impl(table, hyper, idx, nullptr, nullptr, B, FMX_LOSS_NONE, inv_b, fwd, st);
+      if (rc == FMX_OK && !fm_term) {  // NFM: the network's input logit is first-order + bias; the FM logit's buffer holds it
+        hipLaunchKernelGGL(k_first_plus_bias, dim3((B + 255) / 256), dim3(256), 0, st, fwd->logit, fwd->sfirst, table->bias, B);
+        rc = check_launch("fmx_deepfm_stream (k_first_plus_bias)");
+      }
       if (rc == FMX_OK)
         rc = fmx_mlp_section(mlp, loss_kind, fwd->bi, table->kp, fwd->logit, y, B, inv_b, mlp_workspace, nullptr, dz, gbi, table->kp, grads,
                              lr_mlp, loss_out ? loss_out + s : nullptr, st);
       if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
       if (rc == FMX_OK)
-        rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, dz, dz, gbi, B, nullptr, inv_b, nullptr, st, nullptr, 0, fwd->error);
+        rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, dz, fm_term ? dz : nullptr, gbi, B, nullptr, inv_b, nullptr, st, nullptr, 0,
+                         fwd->error);
       if (sd && i == 0 && next_first < n_steps && rc == FMX_OK) {
         if (g >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[(g + 1) & 1], 0);
         rc = sort_group(g + 1, next_first, group_size(g + 1, next_first), sd->stream);

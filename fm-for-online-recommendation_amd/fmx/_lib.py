@@ -108,7 +108,7 @@ def load():
     lib.fmx_mlp_section_workspace_bytes.restype = C.c_int64
     lib.fmx_mlp_section_workspace_bytes.argtypes = [MP, i32]
     lib.fmx_mlp_section.argtypes = [MP, i32, p, i32, p, p, i32, f32, p, p, p, p, i32, p, f32, p, p]
-    lib.fmx_deepfm_stream.argtypes = [TP, HP, i32, MP, i32, p, p, i32, i32, f32, i32, p, i64, p, FP, p, p, p, f32, p, p]
+    lib.fmx_deepfm_stream.argtypes = [TP, HP, i32, MP, i32, i32, p, p, i32, i32, f32, i32, p, i64, p, FP, p, p, p, f32, p, p]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name in I64_RETURNS:

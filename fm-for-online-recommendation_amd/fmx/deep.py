@@ -89,12 +89,14 @@ class DeepFMTrainer:
     def prepare_stream(self, idx_pool, y_pool, loss_out=None, stream=None):
         """-> run(n_steps): the steps of step() over a device-resident pool (step s: batch s mod n_pool) issued from ONE foreign call
         (fmx_deepfm_stream) -- through step() the trainer is bound by its host side (84 us of calls per step for 67 us of
-        kernels at configs[3]).  One rank, the native MLP section, the FM term in the logit (DeepFM); identical results."""
-        if not (self.native and self.world == 1 and self.fm_term and hasattr(self.backend, "e")):
-            raise ValueError("prepare_stream: one rank, native MLP section and the DeepFM logit only; use step()")
+        kernels at configs[3]).  One rank, the native MLP section; DeepFM or NFM (fm_term=False: weights-layout tables); identical results."""
+        if not (self.native and self.world == 1 and hasattr(self.backend, "e")):
+            raise ValueError("prepare_stream: one rank and the native MLP section only; use step()")
         be = self.backend
+        if not self.fm_term and be.e.table.layout != "weights":
+            raise ValueError("prepare_stream: NFM (fm_term=False) needs tables in the weights layout; use step()")
         return be.e.prepare_deepfm_stream(be.hyper, be.rule, self.loss, self.flat, self.gflat, self.k, self.hidden, len(self.layers),
-                                          self.mlp_lr, idx_pool, y_pool, loss_out=loss_out, stream=stream)
+                                          self.mlp_lr, idx_pool, y_pool, loss_out=loss_out, stream=stream, fm_term=self.fm_term)
 
     def _gathered(self, name, local):
         if self.world == 1:

@@ -219,9 +219,10 @@ class FMEngine:
         return run
 
     def prepare_deepfm_stream(self, hyper, rule, loss, params, grads, k, hidden, n_layers, lr_mlp, idx_pool, y_pool, loss_out=None,
-                              stream=None):
+                              stream=None, fm_term=True):
         """-> run(n_steps): the mini-batch DeepFM loop over a resident pool (fmx_deepfm_stream), every argument but the step count
-        bound once; per step forward, MLP section (SGD of the MLP applied in it: lr_mlp), table update, all issued from one call.
+        bound once; per step forward, MLP section (SGD of the MLP applied in it: lr_mlp), table update, all issued from one call
+        (fm_term=False: NFM -- the network's base is first-order + bias; weights-layout tables).
         `params` / `grads`: the flat MLP buffers (W_l then b_l per layer).  The caller keeps the tensors alive and does not grow
         the engine between prepare and run."""
         n_pool, B, F = idx_pool.shape
@@ -232,7 +233,7 @@ class FMEngine:
         m = self._mlp_struct(params, k, hidden, n_layers)
         self._mlp_big_buffers(m, k, hidden, n_layers, B)
         fn, check = self.lib.fmx_deepfm_stream, _lib.check
-        fixed = (self.table.c_struct(), hyper.ref(), _lib.RULES[rule], C.byref(m), _lib.LOSSES[loss], idx_pool.data_ptr(), y_pool.data_ptr(),
+        fixed = (self.table.c_struct(), hyper.ref(), _lib.RULES[rule], C.byref(m), _lib.LOSSES[loss], int(bool(fm_term)), idx_pool.data_ptr(), y_pool.data_ptr(),
                  n_pool, B, 1.0 / B)
         tail = (self.workspace.data_ptr(), self._ws_bytes(), self._mlp_ws.data_ptr(), C.byref(out), self._mlp_dz.data_ptr(),
                 self._mlp_gbi.data_ptr(), grads.data_ptr(), lr_mlp, _ptr(loss_out), self._stream(stream))

@@ -381,8 +381,12 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
  * mlp->params) are scratch the call fills; loss_out [n_steps] or null; workspace: fmx_workspace_bytes(table, B), mlp_workspace:
  * fmx_mlp_section_workspace_bytes(mlp, B).  The result is the one of calling fmx_fm_forward, fmx_mlp_section, fmx_sort_occurrences
  * and fmx_fm_update per step.
- * Replaces: the mini-batch driver loop over DeepFMAdam.fit (reference main_experiment.py:92-105 with deepfm_adam.py:106-119). */
-int fmx_deepfm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const fmx_mlp_t *mlp, int32_t loss_kind,
+ * fm_term: 1 = DeepFM (the FM logit is the network's base and dz also drives the FM term of the rows' gradient); 0 = NFM (base =
+ * first-order sum + bias, written into fwd->logit's buffer; fwd->sfirst required; tables in the weights layout; the rows' gradient
+ * comes through dL/dbi only -- reference nfm_adam.py:78-88,105-118).
+ * Replaces: the mini-batch driver loop over DeepFMAdam.fit / NFMAdam.fit (reference main_experiment.py:92-105 with
+ * deepfm_adam.py:106-119, nfm_adam.py:105-118). */
+int fmx_deepfm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule, const fmx_mlp_t *mlp, int32_t loss_kind, int32_t fm_term,
                       const int32_t *idx_pool, const float *y_pool, int32_t n_pool, int32_t B, float inv_b, int32_t n_steps,
                       void *workspace, int64_t workspace_bytes, void *mlp_workspace, const fmx_fwd_out_t *fwd, float *dz, float *gbi,
                       float *grads, float lr_mlp, float *loss_out, fmx_stream_t stream);

@@ -163,6 +163,42 @@ def test_pickle_and_state_dict_roundtrip(name):
         m.predict([[99] * len(meta["feature_sizes"])], [[1.0] * len(meta["feature_sizes"])])
 
 
+def test_pinned_stager_in_place_and_staged_give_the_same_batches():
+    """PinnedBatchStager: int32 / fp32 arrays pinned where they are (every batch a DMA out of the dataset) against the staged path
+    (typed copy into pinned buffers; taken for int64 indices) and against plain slicing: same batches, ragged tail, real values,
+    more batches than slots; the arrays are usable and unpinned after close()."""
+    from utils.data_preprocess import PinnedBatchStager
+    rng = np.random.default_rng(2)
+    N, F, B = 1000, 7, 96
+    index = rng.integers(0, 50, size=(N, F)).astype(np.int32)
+    label = (rng.uniform(size=N) < 0.5).astype(np.int64)
+    value = rng.normal(size=(N, F)).astype(np.float32)
+    for val in (None, value):
+        a = PinnedBatchStager(index, label, B, value=val, depth=3)
+        b = PinnedBatchStager(index.astype(np.int64), label, B, value=val, depth=2)
+        assert a._src is not None and b._src is None
+        n = 0
+        for (ia, va, ya), (ib, vb, yb) in zip(a, b):
+            lo, hi = n * B, min((n + 1) * B, N)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(ia.cpu().numpy(), index[lo:hi])
+            np.testing.assert_array_equal(ib.cpu().numpy(), index[lo:hi])
+            np.testing.assert_array_equal(ya.cpu().numpy(), label[lo:hi].astype(np.float32))
+            np.testing.assert_array_equal(yb.cpu().numpy(), ya.cpu().numpy())
+            if val is not None:
+                np.testing.assert_array_equal(va.cpu().numpy(), value[lo:hi])
+                np.testing.assert_array_equal(vb.cpu().numpy(), value[lo:hi])
+            else:
+                assert va is None and vb is None
+            n += 1
+        assert n == (N + B - 1) // B
+        a.close()
+        assert a._src is None and not a._registered
+        assert int(index.sum()) > 0                      # still ordinary memory
+    c = PinnedBatchStager(index, label, B, register_in_place=False)
+    assert c._src is None and sum(1 for _ in c) == (N + B - 1) // B
+
+
 @pytest.mark.parametrize("name", ["FMAdam", "DeepFMAdam"])
 def test_tensor_inputs_equal_nested_lists(name):
     """The array / tensor fast path (no list conversion; CUDA int32 tensors used where they lie; Xv = None for all-ones)
@@ -378,10 +414,11 @@ def test_deep_trainer_step_vs_oracle(name, native):
     assert_state_close(got, ref, {kk: sd0[kk] for kk in ref}, what=f"{name} sgd step")
 
 
-def test_deepfm_stream_equals_trainer_steps():
+@pytest.mark.parametrize("fm_term", [True, False])
+def test_deepfm_stream_equals_trainer_steps(fm_term):
     """fmx_deepfm_stream (DeepFMTrainer.prepare_stream: the steps of a pool of batches issued from one foreign call, the sorts in
-    groups on the side stream) against DeepFMTrainer.step on the same batches: tables, MLP parameters and per-step losses
-    identical bits.  B = 256 takes the side-stream path, 13 steps over a pool of 5 batches cross a sort group and wrap the pool;
+    groups on the side stream) against DeepFMTrainer.step on the same batches, DeepFM and NFM (fm_term=False: base = first-order +
+    bias): tables, MLP parameters and per-step losses identical bits.  B = 256 takes the side-stream path, 13 steps over a pool of 5 batches cross a sort group and wrap the pool;
     the step path itself is pinned against the oracle by test_deep_trainer_step_vs_oracle."""
     import fmx
     import torch.nn as nn
@@ -397,7 +434,8 @@ def test_deepfm_stream_equals_trainer_steps():
         table.rows[:, :k + 1] = torch.randn((table.n_rows, k + 1), generator=g, device="cuda") * 0.1
         eng = fmx.FMEngine(table, max_batch=B)
         layers = [nn.Linear(k if j == 0 else H, H).cuda() for j in range(L)]
-        tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=lr), "sgd"), layers, k, table.kp, mlp_lr=lr)
+        table.set_bias_weight(0.3)
+        tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=lr), "sgd"), layers, k, table.kp, mlp_lr=lr, fm_term=fm_term)
         assert tr.native
         idx_d, y_d = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
         losses = torch.zeros(n_steps, device="cuda")
