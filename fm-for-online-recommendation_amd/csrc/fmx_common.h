@@ -34,7 +34,7 @@ struct Tune {
   int inline_fixup = 1;  // FMX_INLINE_FIXUP=0 / fmx_set_option("inline_fixup", 0): partial records are combined by a second
                          // launch (k_fm_fixup) instead of the in-launch hand-off; both give identical bits
   int online_persistent = 1;  // FMX_ONLINE_PERSISTENT=0 / fmx_set_option("online_persistent", 0): fmx_online_run_mlp as per-sample launches
-  int sort_ahead = 8;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..8)
+  int sort_ahead = 16;  // FMX_SORT_AHEAD: batches per side-stream sort launch in fmx_fm_stream (1..16)
   int mlp_chain = 1;          // FMX_MLP_CHAIN=0 / fmx_set_option("mlp_chain", 0): fmx_mlp_section as separate GEMM launches
                               // (forward x L, loss, dgrad x L) instead of k_mlp_chain; same results up to summation order
   int sort_chunked = 1;  // FMX_SORT_CHUNKED / fmx_set_option("sort_chunked", v): 0: one workgroup per field (k_sort_occ) at

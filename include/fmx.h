@@ -148,7 +148,7 @@ const char *fmx_last_error_string(void);
  * status for an unknown name.  Every switch changes HOW the same result is computed; results are identical bits.
  *   "inline_fixup" (default 1)  1: runs that cross 64-occurrence tiles are finished inside k_fm_update by an in-launch
  *                                hand-off; 0: by a second launch (k_fm_fixup).
- *   "sort_ahead"   (default 8)  most batches sorted per side-stream launch in fmx_fm_stream (1..8).
+ *   "sort_ahead"   (default 16) most batches sorted per side-stream launch in fmx_fm_stream / fmx_deepfm_stream (1..16).
  *   "sort_chunked" (default 1)  0: one workgroup per field at every width; 1: k_sort_chunk + k_sort_merge (1,024-composite
  *                                chunks spread over the chip, stable rank merge) from 8,192 composites per field on; 2: from 2,048 on.
  *   "mlp_chain"    (default 1)  0: fmx_mlp_section as separate GEMM launches instead of k_mlp_chain (forward + loss + dgrad chain
@@ -162,9 +162,9 @@ int fmx_sorted_bbits(int B);
 
 /* Bytes of caller-owned device workspace a step of batch size B needs (16-byte aligned).  Layout:
  *   (F below: the number of SORT fields of the table, = n_fields unless large fields are split)
- *   sorted  uint32 [16][F, Bp]       occurrence lists: (local index << bbits) | sample, padded with 0xFFFFFFFF
- *                                    (a ring of 16: fmx_fm_stream sorts up to 8 batches ahead; single steps use the first)
- *   runs    uint32 [8][F, Bp]        Bp >= 2048 only: the chunk-sorted intermediate of the wide sort
+ *   sorted  uint32 [32][F, Bp]       occurrence lists: (local index << bbits) | sample, padded with 0xFFFFFFFF
+ *                                    (a ring of 32: fmx_fm_stream sorts up to 16 batches ahead; single steps use the first)
+ *   runs    uint32 [16][F, Bp]       Bp >= 2048 only: the chunk-sorted intermediate of the wide sort
  *   meta    int32  [F, Bp/64, 2]     per 64-entry tile: does a run come in from / go out to the neighbouring tile; with the
  *                                    in-launch hand-off word 0 is (launch sequence << 4 | states) and is polled by later tiles
  *   parts   float  [F, Bp/64, 2, 2*kp+4]  partial sums of the runs that cross a tile boundary
