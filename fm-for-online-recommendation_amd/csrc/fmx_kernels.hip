@@ -2563,18 +2563,12 @@ int fmx_fm_step(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (int rc = check_workspace(table, B, workspace, workspace_bytes, "fmx_fm_step")) return rc;
   const Workspace w = carve(table, B, workspace);
-  Side *sd = B >= OVERLAP_MIN_BATCH ? side_for_current_device() : nullptr;
-  if (sd) {  // sort beside the forward pass: fork -> {side: sort} || {main: forward} -> join -> update
-    (void)hipEventRecord(sd->fork, st);
-    (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
-    if (int rc = sort_impl(table, idx, B, w.sorted, w.runs, fwd->error, sd->stream)) return rc;
-    (void)hipEventRecord(sd->sorted[0], sd->stream);
-    if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
-    (void)hipStreamWaitEvent(st, sd->sorted[0], 0);
-  } else {
-    if (int rc = sort_impl(table, idx, B, w.sorted, w.runs, fwd->error, st)) return rc;
-    if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
-  }
+  // One stream: sort -> forward -> update.  (Until r3 the sort ran on the side stream beside the forward pass; a dependency that
+  // crosses streams costs 5 - 6 us on the device and four more runtime calls on the host, as much as the overlap of a 7 us forward
+  // with an 18 us sort saves -- and a caller of single steps is host-bound: FMAdam.update_embedding 65 - 73 against 90 - 112 us
+  // per batch, tools/class_surface_profile.py.  Loops over many batches: fmx_fm_stream, where a sort launch covers 16 of them.)
+  if (int rc = sort_impl(table, idx, B, w.sorted, w.runs, fwd->error, st)) return rc;
+  if (int rc = forward_impl(table, hyper, idx, xv, y, B, loss_kind, inv_b, fwd, st)) return rc;
   return update_impl(table, hyper, rule, w, w.sorted, xv, fwd->S, fwd->dz, fwd->dz, nullptr, B, fwd->loss, inv_b, loss_out, st,
                      nullptr, fwd->sample_ld, fwd->error);
 }
