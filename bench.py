@@ -222,11 +222,14 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
     # one GPU: the steps of the pool issued from ONE foreign call (fmx_deepfm_stream) -- through the Python trainer the step is bound
     # by its host side (84 us of calls per step for 67 us of kernels); that path is timed beside it as `through_trainer_step`
     native_loop = None
+    import contextlib
+    work = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+    on_work = (lambda: torch.cuda.stream(work)) if work is not None else contextlib.nullcontext
+    if work is not None:
+        torch.cuda.synchronize()                              # the tables and the pool were written on torch's current stream
     if world == 1 and not owners and getattr(tr, "native", False) and os.environ.get("FMX_DEEPFM_STREAM", "1") == "1":
-        work = torch.cuda.Stream(device=dev)
         loop_losses = torch.zeros(max(min(args.steps, 100), 10), device=dev)
         native_loop = tr.prepare_stream(idx_pool, y_pool, loss_out=loop_losses, stream=work)
-        torch.cuda.synchronize()                              # the tables and the pool were written on torch's current stream
 
     def run(n, first=0):
         out = None
@@ -242,8 +245,9 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
                     tokens[s + 2] = tr.prefetch(idx_pool[(first + s + 2) % N_POOL])
             tr.finish()
             return out
-        for s in range(n):
-            out = tr.step(idx_pool[(first + s) % N_POOL], y_pool[(first + s) % N_POOL])
+        with on_work():                                        # (not torch's legacy default stream: every launch there is ordered against
+            for s in range(n):                                 # every blocking stream of the process, a cross-stream wait each)
+                out = tr.step(idx_pool[(first + s) % N_POOL], y_pool[(first + s) % N_POOL])
         return out
     steps, warm = min(args.steps, 100), min(args.warmup, 10)
     run(warm)
@@ -358,22 +362,28 @@ def bench_class_surface(torch, n_steps=80):
         m.update_embedding(Xi, Xv, Y)
     torch.cuda.synchronize()
     out["nested_lists_samples_per_s"] = 3 * BATCH / (time.perf_counter() - t0)
-    stager = PinnedBatchStager(index, label, BATCH)        # the arrays are pinned in place once; a batch is a DMA out of them
-    for _ in range(3):                                     # warm-up passes (the first pays one-time costs: ~2 ms per batch)
-        for idx_d, xv_d, y_d in stager:
-            m.update_embedding(idx_d, xv_d, y_d)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 0
-    while n < n_steps:
-        for idx_d, xv_d, y_d in stager:
-            m.update_embedding(idx_d, xv_d, y_d)
-            n += 1
-    m.check_index_flag()
-    torch.cuda.synchronize()
-    out["pinned_arrays_samples_per_s"] = n * BATCH / (time.perf_counter() - t0)
-    out["note"] = ("FMAdam.update_embedding at B = 4096 through the Python class; the H2D copy of every batch (the int32 index array "
-                   "pinned in place: no host pass) + the step inside the timed region; one fmx_fm_step call (3 launches) per batch, "
+    def rate(stager):
+        for _ in range(3):                                 # warm-up passes (the first pays one-time costs: ~1-2 ms per batch)
+            for idx_d, xv_d, y_d in stager:
+                m.update_embedding(idx_d, xv_d, y_d)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        while n < n_steps:
+            for idx_d, xv_d, y_d in stager:
+                m.update_embedding(idx_d, xv_d, y_d)
+                n += 1
+        m.check_index_flag()
+        torch.cuda.synchronize()
+        return n * BATCH / (time.perf_counter() - t0)
+    # staged (the default: a typed copy into pinned buffers per batch -- what a stream seen ONCE costs) and pinned in place (no host
+    # pass; only for data passed over repeatedly, as here: the first copy out of freshly pinned pages costs ~0.8 ms per batch)
+    out["pinned_arrays_samples_per_s"] = rate(PinnedBatchStager(index, label, BATCH))
+    st2 = PinnedBatchStager(index, label, BATCH, register_in_place=True)
+    out["pinned_in_place_repeated_passes_samples_per_s"] = rate(st2)
+    st2.close()
+    out["note"] = ("FMAdam.update_embedding at B = 4096 through the Python class; the typed copy into pinned memory (staged) or none "
+                   "(pinned in place), the H2D copy and the step inside the timed region; one fmx_fm_step call (3 launches) per batch, "
                    "Python-bound")
     return out
 

@@ -203,12 +203,15 @@ class PinnedBatchStager:
     The tensors of a batch are valid until `depth` further batches have been drawn (their buffers are reused; the copy into
     a buffer waits for the work that was current on the consumer's stream when its previous batch was handed out plus
     everything enqueued until the next draw).  A last partial batch is yielded unless drop_last.  feature_sizes: if given,
-    indices are range-checked on the host (vectorised), IndexError like nn.Embedding.  register_in_place (default): int32 index /
-    fp32 value arrays (C-contiguous) are pinned where they are and every batch is a DMA out of them; they must not be freed or
-    resized while the stager lives (it keeps references) and are unpinned by close()."""
+    indices are range-checked on the host (vectorised), IndexError like nn.Embedding.  register_in_place=True: int32 index /
+    fp32 value arrays (C-contiguous) are pinned where they are (hipHostRegister) and every batch is a DMA out of them -- no host pass,
+    70 against 93 us per 4096 x 39 batch through FMAdam.update_embedding -- but the FIRST copy out of freshly pinned pages costs
+    ~0.8 ms per batch (tools/class_surface_passes.py): worth it for a dataset that is passed over several times, a loss for a
+    stream seen once, hence off by default.  The arrays must not be freed or resized while the stager lives (it keeps
+    references); close() unpins them."""
 
     def __init__(self, index, label, batch_size, device=None, value=None, depth=2, drop_last=False, feature_sizes=None,
-                 register_in_place=True):
+                 register_in_place=False):
         import torch
         self.torch = torch
         self.index = np.asarray(index)
@@ -233,9 +236,10 @@ class PinnedBatchStager:
         self._copy = torch.cuda.Stream(device=self.device) if pin else None
         self._ready = [torch.cuda.Event() if pin else None for _ in range(self.depth)]
         self._free = [torch.cuda.Event() if pin else None for _ in range(self.depth)]
-        # Arrays that already have the device's types are PINNED IN PLACE (hipHostRegister through torch's runtime binding): a batch
-        # is then a DMA straight out of the dataset -- no host pass at all (the typed memcpy into a pinned buffer was 65 of the 75 us
-        # this class cost per 4096 x 39 batch: tools/class_surface_profile.py).  Other dtypes keep the staged path below.
+        # register_in_place: arrays that already have the device's types are PINNED WHERE THEY ARE (hipHostRegister through torch's
+        # runtime binding): a batch is then a DMA straight out of the dataset -- no host pass at all (the typed memcpy into a pinned
+        # buffer is 65 of the 75 us this class costs per 4096 x 39 batch: tools/class_surface_profile.py).  Other dtypes keep the
+        # staged path below.
         self._registered = []
         self._src = None
         if pin and register_in_place:

@@ -174,7 +174,7 @@ def test_pinned_stager_in_place_and_staged_give_the_same_batches():
     label = (rng.uniform(size=N) < 0.5).astype(np.int64)
     value = rng.normal(size=(N, F)).astype(np.float32)
     for val in (None, value):
-        a = PinnedBatchStager(index, label, B, value=val, depth=3)
+        a = PinnedBatchStager(index, label, B, value=val, depth=3, register_in_place=True)
         b = PinnedBatchStager(index.astype(np.int64), label, B, value=val, depth=2)
         assert a._src is not None and b._src is None
         n = 0
@@ -195,7 +195,7 @@ def test_pinned_stager_in_place_and_staged_give_the_same_batches():
         a.close()
         assert a._src is None and not a._registered
         assert int(index.sum()) > 0                      # still ordinary memory
-    c = PinnedBatchStager(index, label, B, register_in_place=False)
+    c = PinnedBatchStager(index, label, B)
     assert c._src is None and sum(1 for _ in c) == (N + B - 1) // B
 
 
