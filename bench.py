@@ -354,6 +354,16 @@ def bench_class_surface(torch, n_steps=80):
     m = FMAdam(CRITEO_SIZES, embedding_size=K_EMB, n=1e-4)
     m.strict_index_check = False
     out = {}
+    # on a stream of its own: on torch's legacy default stream every launch is ordered against every other blocking stream of the
+    # process (the copy stream of the stager, this bench's work stream): a cross-stream wait per launch (18 against 48 M samples/s)
+    torch.cuda.synchronize()
+    own = torch.cuda.Stream()
+    with torch.cuda.stream(own):
+        return _class_surface_body(torch, m, index, label, n_steps, out)
+
+
+def _class_surface_body(torch, m, index, label, n_steps, out):
+    from utils.data_preprocess import PinnedBatchStager
     Xi, Xv, Y = index[:BATCH].tolist(), [[1] * F for _ in range(BATCH)], label[:BATCH].tolist()
     m.update_embedding(Xi, Xv, Y)
     torch.cuda.synchronize()
