@@ -455,6 +455,51 @@ def test_deepfm_stream_equals_trainer_steps(fm_term):
     assert np.all(np.isfinite(results[0][2])) and results[0][2].std() > 0
 
 
+def test_deepfm_stream_full_size_equals_trainer_steps_and_is_deterministic():
+    """BASELINE configs[3] at its full size through fmx_deepfm_stream (Criteo vocabulary R = 1,006,628, k = 16, 3 x 256, B = 4096, SGD):
+    19 steps over a pool of 6 batches -- two sort groups, the pool wrapped three times -- against DeepFMTrainer.step on the same
+    batches (whose single step test_deep_trainer_full_size_step_vs_oracle pins against the oracle): tables, MLP parameters and losses
+    identical bits; a second run of the loop from the same state gives the same bits again; rows no batch touches do not change."""
+    import fmx
+    import torch.nn as nn
+    sizes = [63, 113, 126, 51, 224, 148, 100, 79, 104, 9, 32, 57, 82, 1457, 555, 176373, 129683, 305, 19, 11887, 632, 3, 41738,
+             5170, 175446, 3170, 27, 11356, 165602, 10, 4641, 2030, 4, 172761, 18, 15, 57903, 86, 44549]
+    k, L, H, B, lr, n_pool, n_steps = 16, 3, 256, 4096, 1e-3, 6, 19
+    rng = np.random.default_rng(21)
+    idx = np.stack([np.stack([rng.integers(0, s, size=B) for s in sizes], axis=1) for _ in range(n_pool)]).astype(np.int32)
+    y = (rng.uniform(size=(n_pool, B)) < 0.3).astype(np.float32)
+    results = []
+    for mode in ("steps", "stream", "stream"):
+        torch.manual_seed(5)
+        table = fmx.FlatTable(sizes, k, layout="weights")
+        g = torch.Generator(device="cuda").manual_seed(9)
+        table.rows[:, :k + 1] = torch.randn((table.n_rows, k + 1), generator=g, device="cuda") * 0.1
+        rows0 = table.rows.clone()
+        eng = fmx.FMEngine(table, max_batch=B)
+        layers = [nn.Linear(k if j == 0 else H, H).cuda() for j in range(L)]
+        tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=lr), "sgd"), layers, k, table.kp, mlp_lr=lr)
+        idx_d, y_d = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
+        losses = torch.zeros(n_steps, device="cuda")
+        if mode == "steps":
+            for s in range(n_steps):
+                losses[s] = tr.step(idx_d[s % n_pool], y_d[s % n_pool])
+        else:
+            tr.prepare_stream(idx_d, y_d, loss_out=losses)(n_steps)
+        torch.cuda.synchronize()
+        eng.check_error_flag()
+        results.append((table.rows.cpu().numpy().copy(), tr.flat.cpu().numpy().copy(), losses.cpu().numpy().copy()))
+    for other in results[1:]:
+        for a, b, what in zip(results[0], other, ("tables", "MLP parameters", "losses")):
+            assert np.array_equal(a, b), what
+    touched = np.zeros(table.n_rows, dtype=bool)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    for f in range(len(sizes)):
+        touched[offs[f] + np.unique(idx[:, :, f])] = True
+    changed = (results[0][0] != rows0.cpu().numpy()).any(axis=1)
+    assert not changed[~touched].any() and changed[touched].mean() > 0.99
+    assert np.all(np.isfinite(results[0][2])) and results[0][2][-1] < results[0][2][0]
+
+
 def test_deep_trainer_full_size_step_vs_oracle():
     """BASELINE configs[3] END TO END at its full size: one online DeepFM step (Criteo vocabulary R = 1,006,628, k = 16,
     3 x 256 relu MLP, B = 4096, SGD lr 1e-3) through fmx.DeepFMTrainer -- sort, forward, the MLP section (k_mlp_chain +
