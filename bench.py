@@ -63,6 +63,20 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
+_WORK = {}
+
+
+def work_stream(torch, dev):
+    """ONE stream of its own for every loop of this process (not torch's legacy default stream, which is ordered against every
+    blocking stream and slow to enqueue on).  One, not one per probe: HIP spreads the streams of a process over a few hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default), and a loop whose stream lands on the queue of the library's side stream runs BEHIND the sorts
+    it should run beside -- the fourth stream created did: 32-80 instead of 21 us per step (tools/zipf_trace.sh)."""
+    key = (dev.type, dev.index)
+    if key not in _WORK:
+        _WORK[key] = torch.cuda.Stream(device=dev)
+    return _WORK[key]
+
+
 def mlp_section_probe(fmx, torch, dev, B=4096, k=16, H=256, L=3, reps=200):
     """fmx_mlp_section alone (BASELINE configs[3]'s network at the bench's batch): HIP events on the launch stream around `reps`
     back-to-back calls -> the `roofline` object of secondary.deepfm (bound: the fp32 MFMA peak, 157.3 TFLOP/s)."""
@@ -76,7 +90,7 @@ def mlp_section_probe(fmx, torch, dev, B=4096, k=16, H=256, L=3, reps=200):
     m = fmx._lib.Mlp(params.data_ptr(), L, k, H, 0)
     ws = torch.empty(int(lib.fmx_mlp_section_workspace_bytes(C.byref(m), B)) // 4, device=dev)
     dz, gbi, loss = torch.empty(B, device=dev), torch.empty(B, k, device=dev), torch.zeros(1, device=dev)
-    st = torch.cuda.Stream(device=dev)
+    st = work_stream(torch, dev)
     torch.cuda.synchronize()
 
     def call():
@@ -113,7 +127,7 @@ def fm_loop_probe(fmx, torch, dev, sizes, zipf, steps=400, warm=100):
     idx_np, y_np = synth_pool(N_POOL, BATCH, sizes, SEED + 7, zipf=zipf)
     idx_pool, y_pool = torch.from_numpy(idx_np).to(dev), torch.from_numpy(y_np).to(dev)
     loss = torch.zeros(max(steps, warm), device=dev)
-    work = torch.cuda.Stream(device=dev)
+    work = work_stream(torch, dev)
     torch.cuda.synchronize()
     run = eng.prepare_stream(hyper, "ftrl", "logits", idx_pool, y_pool, loss, stream=work)
     run(warm)
@@ -223,7 +237,7 @@ def bench_deepfm(args, fmx, torch, dist, world, rank, dev, rehearsal):
     # by its host side (84 us of calls per step for 67 us of kernels); that path is timed beside it as `through_trainer_step`
     native_loop = None
     import contextlib
-    work = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+    work = work_stream(torch, dev) if dev.type == "cuda" else None
     on_work = (lambda: torch.cuda.stream(work)) if work is not None else contextlib.nullcontext
     if work is not None:
         torch.cuda.synchronize()                              # the tables and the pool were written on torch's current stream
@@ -357,7 +371,7 @@ def bench_class_surface(torch, n_steps=80):
     # on a stream of its own: on torch's legacy default stream every launch is ordered against every other blocking stream of the
     # process (the copy stream of the stager, this bench's work stream): a cross-stream wait per launch (18 against 48 M samples/s)
     torch.cuda.synchronize()
-    own = torch.cuda.Stream()
+    own = work_stream(torch, torch.device("cuda", torch.cuda.current_device()))
     with torch.cuda.stream(own):
         return _class_surface_body(torch, m, index, label, n_steps, out)
 
@@ -388,8 +402,9 @@ def _class_surface_body(torch, m, index, label, n_steps, out):
         return n * BATCH / (time.perf_counter() - t0)
     # staged (the default: a typed copy into pinned buffers per batch -- what a stream seen ONCE costs) and pinned in place (no host
     # pass; only for data passed over repeatedly, as here: the first copy out of freshly pinned pages costs ~0.8 ms per batch)
-    out["pinned_arrays_samples_per_s"] = rate(PinnedBatchStager(index, label, BATCH))
-    st2 = PinnedBatchStager(index, label, BATCH, register_in_place=True)
+    st1 = PinnedBatchStager(index, label, BATCH)
+    out["pinned_arrays_samples_per_s"] = rate(st1)
+    st2 = PinnedBatchStager(index, label, BATCH, register_in_place=True, copy_stream=st1._copy)   # (one copy stream: see work_stream)
     out["pinned_in_place_repeated_passes_samples_per_s"] = rate(st2)
     st2.close()
     out["note"] = ("FMAdam.update_embedding at B = 4096 through the Python class; the typed copy into pinned memory (staged) or none "
@@ -535,7 +550,7 @@ def main():
         # ---- one GPU: the online loop of fmx_fm_stream over the resident pool.  Warm-up, then EXACTLY K timed steps ----
         # the loop runs on a stream of its own (the legacy default stream is slow to enqueue on) through a prepared call: the
         # structs, pointers and the stream handle are bound once, a call is one foreign call (FMEngine.prepare_stream)
-        work = torch.cuda.Stream(device=dev)
+        work = work_stream(torch, dev)
         barrier()
         run_loop = eng.prepare_stream(hyper, RULE, "logits", idx_pool, y_pool, loss_buf, stream=work)
         run_loop(args.warmup)
@@ -582,7 +597,7 @@ def main():
         #      low-rank factors (idx, S, dlogit) over RCCL, identical row-reduced update of the replicas ----
         dp = None if owner_mode else fmx.DataParallelFM(fmx.HipBackend(eng, hyper, RULE, "logits"))
         fo, owner_path = None, None
-        work = torch.cuda.Stream(device=dev)          # not the legacy default stream (slow to enqueue on)
+        work = work_stream(torch, dev)                # not the legacy default stream (slow to enqueue on)
         if owner_mode:
             # the step as ONE C call with the library's own RCCL communicator (fmx_owner_step) where every rank has a GPU of its
             # own; agreed on by all ranks (a rank that cannot set it up takes everybody to the torch.distributed form of the

@@ -211,7 +211,7 @@ class PinnedBatchStager:
     references); close() unpins them."""
 
     def __init__(self, index, label, batch_size, device=None, value=None, depth=2, drop_last=False, feature_sizes=None,
-                 register_in_place=False):
+                 register_in_place=False, copy_stream=None):
         import torch
         self.torch = torch
         self.index = np.asarray(index)
@@ -233,7 +233,10 @@ class PinnedBatchStager:
                       torch.empty((self.B,), dtype=torch.float32, device=self.device),
                       None if self.value is None else torch.empty((self.B, self.F), dtype=torch.float32, device=self.device))
                      for _ in range(self.depth)]
-        self._copy = torch.cuda.Stream(device=self.device) if pin else None
+        # copy_stream: reuse one across stagers -- every new stream of a process takes the next of a few hardware queues
+        # (GPU_MAX_HW_QUEUES, 4 by default) and may land on the queue the consumer computes on, where the copies then run between the
+        # kernels instead of beside them
+        self._copy = (copy_stream if copy_stream is not None else torch.cuda.Stream(device=self.device)) if pin else None
         self._ready = [torch.cuda.Event() if pin else None for _ in range(self.depth)]
         self._free = [torch.cuda.Event() if pin else None for _ in range(self.depth)]
         # register_in_place: arrays that already have the device's types are PINNED WHERE THEY ARE (hipHostRegister through torch's
