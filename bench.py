@@ -16,9 +16,12 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-# The data-parallel step keeps several streams busy (main, two prefetch streams, RCCL's): with the runtime's default of 4
-# hardware queues per process two of them share a queue and a prefetched sort waits behind the step it should overlap
-# (77 vs 110 us per 16,384-sample step on one GPU).  Must be set before the HIP runtime starts.
+# Hardware queues per process (must be set before the HIP runtime starts).  The runtime's default is 4; with it two of the streams
+# of the multi-GPU step (main, prefetch, RCCL's) share a queue and a prefetched sort waits behind the step it should overlap (77 vs
+# 110 us per 16,384-sample step, replicated mode rehearsed on one GPU), and the Python paths that keep a torch side stream beside
+# the work stream read a quarter of their rate (trainer step 13.7 vs 51 M samples/s).  With 8 the FOURTH and ELEVENTH stream a
+# process creates land on the queue of the library's side stream and a loop there runs behind the sorts (89 instead of 21 us per
+# step; with 16 queues every fourth stream; tools/queue_alias.py) -- hence work_stream() below: ONE stream for every loop.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.join(ROOT, "fm-for-online-recommendation_amd"))
 sys.path.insert(0, ROOT)
@@ -68,9 +71,10 @@ _WORK = {}
 
 def work_stream(torch, dev):
     """ONE stream of its own for every loop of this process (not torch's legacy default stream, which is ordered against every
-    blocking stream and slow to enqueue on).  One, not one per probe: HIP spreads the streams of a process over a few hardware queues
-    (GPU_MAX_HW_QUEUES, 4 by default), and a loop whose stream lands on the queue of the library's side stream runs BEHIND the sorts
-    it should run beside -- the fourth stream created did: 32-80 instead of 21 us per step (tools/zipf_trace.sh)."""
+    blocking stream and slow to enqueue on).  One, not one per probe: HIP spreads the streams of a process over its hardware queues,
+    and a loop whose stream lands on the queue of the library's side stream runs BEHIND the sorts it should run beside -- with
+    GPU_MAX_HW_QUEUES = 8 the fourth and the eleventh stream a process created did: 32-89 instead of 21 us per step
+    (tools/queue_alias.py, tools/zipf_trace.sh)."""
     key = (dev.type, dev.index)
     if key not in _WORK:
         _WORK[key] = torch.cuda.Stream(device=dev)

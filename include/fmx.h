@@ -22,9 +22,10 @@
  *   - return value: 0 on success, a negative fmx_status otherwise; the message for the calling thread is
  *     available from fmx_last_error_string();
  *   - streams: fmx_fm_stream / fmx_deepfm_stream sort on a library-owned low-priority side stream beside the caller's stream.  HIP maps
- *     the streams of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4): a caller's stream that shares a queue with
- *     the side stream runs BEHIND the sorts (same results, 1.5 - 4 x the time per step).  Keep the number of streams of the process
- *     small (reuse one per loop) or raise GPU_MAX_HW_QUEUES.  The legacy default stream (NULL) is detoured through a library-owned one.
+ *     the streams of a process onto its hardware queues: a caller's stream that shares a queue with the side stream runs BEHIND the
+ *     sorts (same results, 1.5 - 4 x the time per step).  Measured (tools/queue_alias.py): never with the runtime's default
+ *     GPU_MAX_HW_QUEUES = 4; with 8 for the 4th and 11th stream a process creates, with 16 for every fourth.  Reuse one stream per
+ *     loop.  The legacy default stream (NULL) is detoured through a library-owned one.
  *   - the library never throws.  Thread safety: calls on different tables / workspaces / streams may run concurrently;
  *     the mutable process state is (a)-(c) above plus the thread-local error string;
  *   - device-side conditions are reported through the caller's int32 error word (fmx_fwd_out_t.error and the `error`
