@@ -455,6 +455,42 @@ def test_deepfm_stream_equals_trainer_steps(fm_term):
     assert np.all(np.isfinite(results[0][2])) and results[0][2].std() > 0
 
 
+def test_deepfm_stream_rejects_what_it_does_not_take():
+    """fmx_deepfm_stream / DeepFMTrainer.prepare_stream: NFM on FTRL-layout tables, a too-small workspace, per-sample records
+    (sample_ld != 0) and null arguments end in a status code (or a ValueError before the call), never in a launch."""
+    import ctypes as C
+    import fmx
+    import torch.nn as nn
+    sizes, k, H, L, B = [50, 7, 300], 16, 256, 2, 64
+    idx = torch.zeros((2, B, len(sizes)), dtype=torch.int32, device="cuda")
+    y = torch.zeros((2, B), device="cuda")
+    table = fmx.FlatTable(sizes, k, layout="ftrl", ftrl=dict(alpha=0.05, beta=1.0, l1=0.0, l2=0.0))
+    eng = fmx.FMEngine(table, max_batch=B)
+    layers = [nn.Linear(k if j == 0 else H, H).cuda() for j in range(L)]
+    tr = fmx.DeepFMTrainer(fmx.HipDeepBackend(eng, fmx.Hyper(lr=0.01), "ftrl"), layers, k, table.kp, mlp_lr=0.01, fm_term=False)
+    with pytest.raises(ValueError):
+        tr.prepare_stream(idx, y)                                    # NFM needs the weights layout
+    lib = fmx._lib.load()
+    wt = fmx.FlatTable(sizes, k, layout="weights")
+    e2 = fmx.FMEngine(wt, max_batch=B)
+    tr2 = fmx.DeepFMTrainer(fmx.HipDeepBackend(e2, fmx.Hyper(lr=0.01), "sgd"), layers, k, wt.kp, mlp_lr=0.01)
+    run = tr2.prepare_stream(idx, y)
+    run(0)                                                           # no steps: no launch, no error
+    out = e2._fwd_out(want_first=False, want_bi=True)
+    m = e2._mlp_struct(tr2.flat, k, H, L)
+    args = lambda **kw: [kw.get("table", wt.c_struct()), fmx.Hyper(lr=0.01).ref(), fmx._lib.RULES["sgd"], C.byref(m), fmx._lib.LOSSES["logits"], 1,
+                         idx.data_ptr(), y.data_ptr(), 2, B, 1.0 / B, 1, e2.workspace.data_ptr(), kw.get("ws_bytes", e2._ws_bytes()),
+                         e2._mlp_ws.data_ptr(), C.byref(kw.get("out", out)), kw.get("dz", e2._mlp_dz.data_ptr()), e2._mlp_gbi.data_ptr(),
+                         tr2.gflat.data_ptr(), 0.01, None, None]
+    assert lib.fmx_deepfm_stream(*args(ws_bytes=64)) == fmx._lib.ERR_SHAPE
+    assert lib.fmx_deepfm_stream(*args(dz=None)) == fmx._lib.ERR_ARG
+    rec = e2._fwd_out(want_first=False, want_bi=True)
+    rec.sample_ld = 24
+    assert lib.fmx_deepfm_stream(*args(out=rec)) == fmx._lib.ERR_ARG
+    torch.cuda.synchronize()
+    e2.check_error_flag()
+
+
 def test_deepfm_stream_full_size_equals_trainer_steps_and_is_deterministic():
     """BASELINE configs[3] at its full size through fmx_deepfm_stream (Criteo vocabulary R = 1,006,628, k = 16, 3 x 256, B = 4096, SGD):
     19 steps over a pool of 6 batches -- two sort groups, the pool wrapped three times -- against DeepFMTrainer.step on the same
