@@ -56,6 +56,30 @@ struct Comm {
 };
 int comm_all_gather(Comm *c, int which, const void *send, void *recv, size_t count, hipStream_t st);
 int comm_exchange_blocks(Comm *c, const float *send, float *recv, size_t per, hipStream_t st);
+
+// ---- the fixed-order reduction of the MLP's partial weight gradients (k_mlp_reduce, or carried by k_fm_update_rider) ----
+constexpr int MLP_BIG_MAX_L = 8;
+struct MlpReduceArgs {
+  const float *parts[MLP_BIG_MAX_L];  // [n_split, out_l, ldp_l]
+  int out_dim[MLP_BIG_MAX_L], in_dim[MLP_BIG_MAX_L], ldp[MLP_BIG_MAX_L];
+  long long grad_off[MLP_BIG_MAX_L];  // offset of W_l in the flat buffer; b_l follows W_l
+  float *grads;
+  float *params;  // with lr != 0: params -= lr * grad in the same pass (single-rank SGD)
+  float lr;
+  int n_split[MLP_BIG_MAX_L], n_layers;
+  const float *loss_b;
+  float *loss_out;
+  int B;
+  float inv_b;
+};
+// fmx_mlp_section without its last launch: `deferred` receives the arguments of the reduction instead, for a caller that carries
+// its blocks in another launch of the same stream (fmx_deepfm_stream: inside the table update's) or launches it itself
+// (mlp_launch_reduce).  Defined in fmx_mlp.hip.
+int mlp_section_deferred_reduce(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, int32_t ld_bi, const float *base, const float *y, int32_t B,
+                                float inv_b, void *workspace, float *logit_out, float *dz_out, float *gbi_out, int32_t ld_gbi, float *grads,
+                                float lr_apply, float *loss_out, hipStream_t st, MlpReduceArgs *deferred);
+void mlp_launch_reduce(const MlpReduceArgs &a, hipStream_t st);
+int mlp_reduce_blocks_per_layer(const MlpReduceArgs &a, int threads);
 }  // namespace fmxd
 using namespace fmxd;
 
@@ -223,5 +247,59 @@ __device__ float block_sum(const float *src, int n, int ld, float *sm) {
 }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Block `block` of `n_blocks` of layer l: one thread per 4 consecutive columns of one row of the layer's partial [out, ldp] (ldp a
+// multiple of 4: the weight columns, the bias column `in`, padding): 16-byte loads of up to 16 splits in flight, summed in the
+// order z = 0, 1, ...; block 0 of layer 0 also reduces the loss.  Any workgroup width (the table update's is 64 or 128 or 256).
+__device__ __forceinline__ void mlp_reduce_block(const MlpReduceArgs &a, int l, int block, int n_blocks) {
+  const int out = a.out_dim[l], in = a.in_dim[l], ldp = a.ldp[l], ns = a.n_split[l];
+  const int groups = ldp >> 2;
+  const long long n = (long long)out * groups;
+  const float *p = a.parts[l];
+  const size_t zs = (size_t)out * ldp;
+  for (long long i = (long long)block * blockDim.x + threadIdx.x; i < n; i += (long long)n_blocks * blockDim.x) {
+    const int m = (int)(i / groups), c = (int)(i - (long long)m * groups) * 4;
+    const float *q = p + (size_t)m * ldp + c;
+    // the parameters this thread updates, requested with the partials instead of behind their sum (a dependent round trip less);
+    // a group of four weight columns is 16 contiguous, 16-byte aligned bytes of W_l when in % 4 == 0 (else the scalar path below)
+    const bool vec4 = a.lr != 0.f && c + 3 < in && (in & 3) == 0 && (a.grad_off[l] & 3) == 0;
+    float4 pv = {0.f, 0.f, 0.f, 0.f};
+    if (vec4) pv = *reinterpret_cast<const float4 *>(a.params + a.grad_off[l] + (long long)m * in + c);
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < ns; z0 += 16) {
+      float4 r[16];
+#pragma unroll
+      for (int z = 0; z < 16; ++z)
+        if (z0 + z < ns) r[z] = *reinterpret_cast<const float4 *>(q + (size_t)(z0 + z) * zs);
+#pragma unroll
+      for (int z = 0; z < 16; ++z)
+        if (z0 + z < ns) {
+          s.x += r[z].x;
+          s.y += r[z].y;
+          s.z += r[z].z;
+          s.w += r[z].w;
+        }
+    }
+    if (vec4) {
+      const long long o = a.grad_off[l] + (long long)m * in + c;
+      *reinterpret_cast<float4 *>(a.grads + o) = s;
+      *reinterpret_cast<float4 *>(a.params + o) = float4{pv.x - a.lr * s.x, pv.y - a.lr * s.y, pv.z - a.lr * s.z, pv.w - a.lr * s.w};
+      continue;
+    }
+    const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (c + j > in) break;  // padding
+      const long long o = c + j < in ? a.grad_off[l] + (long long)m * in + c + j : a.grad_off[l] + (long long)out * in + m;
+      a.grads[o] = v[j];
+      if (a.lr != 0.f) a.params[o] -= a.lr * v[j];
+    }
+  }
+  if (block == 0 && l == 0 && a.loss_out) {
+    __shared__ float sm[256];
+    const float ls = block_sum(a.loss_b, a.B, 1, sm);
+    if (threadIdx.x == 0) a.loss_out[0] = ls * a.inv_b;
+  }
+}
 
 }  // namespace

@@ -1009,6 +1009,21 @@ __global__ __launch_bounds__(256) void k_fm_update(UpdArgs a) {
   update_body<LPR, LAYOUT, RULE, HAS_GBI, INL>(a, blockIdx.x);
 }
 
+// The same launch with a RIDER: the workgroups behind the update's own carry the fixed-order reduction of the MLP's partial weight
+// gradients (mlp_reduce_block: a few hundred latency-bound waves that the table update neither feeds nor needs -- both wait only for
+// the launches in front).  fmx_deepfm_stream: one launch and 6 - 7 us less per step than k_mlp_reduce as a launch of its own in front
+// of the update; on a second stream the same overlap lost to the cross-stream hand-off.  Identical results.
+template <int LPR, int LAYOUT, int RULE, bool HAS_GBI>
+__global__ __launch_bounds__(256) void k_fm_update_rider(UpdArgs a, MlpReduceArgs r, int n_update_blocks, int rider_blocks_per_layer) {
+  __builtin_amdgcn_s_setprio(3);
+  if ((int)blockIdx.x >= n_update_blocks) {
+    const int rb = (int)blockIdx.x - n_update_blocks;
+    mlp_reduce_block(r, rb / rider_blocks_per_layer, rb % rider_blocks_per_layer, rider_blocks_per_layer);
+    return;
+  }
+  update_body<LPR, LAYOUT, RULE, HAS_GBI, true>(a, blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_fm_online: the reference's online protocol on a device-resident stream (pure FM)
 // ------------------------------------------------------------------------------------------------------------
@@ -1872,6 +1887,25 @@ void launch_update(const UpdArgs &a, int rule, hipStream_t st) {
 }
 
 template <int LPR>
+void launch_update_rider(const UpdArgs &a, int rule, const MlpReduceArgs &r, hipStream_t st) {  // HAS_GBI, in-launch hand-off
+  const int tiles = a.F * (a.Bp >> 6);
+  const int wpb = tune().wpb_upd;
+  const int n_upd = (tiles + wpb - 1) / wpb + red_slices(a.B), per = mlp_reduce_blocks_per_layer(r, 64 * wpb);
+  const dim3 grid(n_upd + per * r.n_layers), block(64 * wpb);
+  switch (rule) {
+    case FMX_RULE_SIGNADAM:
+      hipLaunchKernelGGL((k_fm_update_rider<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SIGNADAM, true>), grid, block, 0, st, a, r, n_upd, per);
+      break;
+    case FMX_RULE_SGD:
+      hipLaunchKernelGGL((k_fm_update_rider<LPR, FMX_LAYOUT_WEIGHTS, FMX_RULE_SGD, true>), grid, block, 0, st, a, r, n_upd, per);
+      break;
+    default:
+      hipLaunchKernelGGL((k_fm_update_rider<LPR, FMX_LAYOUT_FTRL, FMX_RULE_FTRL, true>), grid, block, 0, st, a, r, n_upd, per);
+      break;
+  }
+}
+
+template <int LPR>
 void launch_fixup(const UpdArgs &a, int rule, hipStream_t st) {
   const int tiles = a.F * (a.Bp >> 6);
   const int wpb = tune().wpb_upd;
@@ -2091,9 +2125,22 @@ int update_impl(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_t rule
                 const float *S, const float *dz_first, const float *dz_bi, const float *gbi, int32_t B,
                 const float *loss_b, float inv_b, float *loss_out, hipStream_t st,
                 int32_t *step_counter = nullptr, int32_t sample_ld = 0,
-                int32_t *err_flag = nullptr) {
+                int32_t *err_flag = nullptr, const MlpReduceArgs *rider = nullptr) {
   const UpdArgs a = fill_upd(table, hyper, w, sorted, xv, S, dz_first, dz_bi, gbi, B, loss_b, inv_b, loss_out, step_counter,
                              sample_ld, err_flag);
+  if (rider) {
+    if (gbi != nullptr && tune().inline_fixup && !is_capturing(st)) {  // the one-launch form of the update: the rider goes with it
+      switch (lpr_of(table->kp)) {
+        case 1: launch_update_rider<1>(a, rule, *rider, st); break;
+        case 2: launch_update_rider<2>(a, rule, *rider, st); break;
+        case 4: launch_update_rider<4>(a, rule, *rider, st); break;
+        case 8: launch_update_rider<8>(a, rule, *rider, st); break;
+        default: launch_update_rider<16>(a, rule, *rider, st); break;
+      }
+      return check_launch("k_fm_update_rider");
+    }
+    mlp_launch_reduce(*rider, st);  // otherwise the reduction as a launch of its own, in front
+  }
   switch (lpr_of(table->kp)) {
     case 1: launch_update_pair<1>(a, rule, gbi != nullptr, st); break;
     case 2: launch_update_pair<2>(a, rule, gbi != nullptr, st); break;
@@ -2449,13 +2496,14 @@ int fmx_deepfm_stream(const fmx_table_t *table, const fmx_hyper_t *hyper, int32_
         hipLaunchKernelGGL(k_first_plus_bias, dim3((B + 255) / 256), dim3(256), 0, st, fwd->logit, fwd->sfirst, table->bias, B);
         rc = check_launch("fmx_deepfm_stream (k_first_plus_bias)");
       }
+      MlpReduceArgs red;  // the section's last launch rides inside the table update's (k_fm_update_rider)
       if (rc == FMX_OK)
-        rc = fmx_mlp_section(mlp, loss_kind, fwd->bi, table->kp, fwd->logit, y, B, inv_b, mlp_workspace, nullptr, dz, gbi, table->kp, grads,
-                             lr_mlp, loss_out ? loss_out + s : nullptr, st);
+        rc = mlp_section_deferred_reduce(mlp, loss_kind, fwd->bi, table->kp, fwd->logit, y, B, inv_b, mlp_workspace, nullptr, dz, gbi, table->kp,
+                                         grads, lr_mlp, loss_out ? loss_out + s : nullptr, st, &red);
       if (sd && i == 0) (void)hipStreamWaitEvent(st, sd->sorted[g & 1], 0);
       if (rc == FMX_OK)
         rc = update_impl(table, hyper, rule, w, sorted, nullptr, fwd->S, dz, fm_term ? dz : nullptr, gbi, B, nullptr, inv_b, nullptr, st, nullptr, 0,
-                         fwd->error);
+                         fwd->error, &red);
       if (sd && i == 0 && next_first < n_steps && rc == FMX_OK) {
         if (g >= 1) (void)hipStreamWaitEvent(sd->stream, sd->consumed[(g + 1) & 1], 0);
         rc = sort_group(g + 1, next_first, group_size(g + 1, next_first), sd->stream);

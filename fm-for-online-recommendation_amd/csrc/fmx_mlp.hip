@@ -70,13 +70,27 @@ int64_t fmx_mlp_section_workspace_bytes(const fmx_mlp_t *mlp, int32_t B) {
   return (int64_t)mlp_big_carve(mlp, B, nullptr).bytes;
 }
 
+// blocks per layer of the reduction for workgroups of `threads` threads: one 16-byte group per thread, at most 256 blocks
+extern "C++" int fmxd::mlp_reduce_blocks_per_layer(const MlpReduceArgs &a, int threads) {
+  long long biggest = 0;
+  for (int l = 0; l < a.n_layers; ++l) {
+    const long long n = (long long)a.out_dim[l] * (a.ldp[l] >> 2);
+    if (n > biggest) biggest = n;
+  }
+  const long long bx = (biggest + threads - 1) / threads;
+  return (int)(bx > 256 ? 256 : bx < 1 ? 1 : bx);
+}
+extern "C++" void fmxd::mlp_launch_reduce(const MlpReduceArgs &a, hipStream_t st) {
+  hipLaunchKernelGGL(k_mlp_reduce, dim3(mlp_reduce_blocks_per_layer(a, 256), a.n_layers), dim3(256), 0, st, a);
+}
+
 // the backward of the mini-batch MLP from dH_{L-1} (already in w.dH): the dgrad chain (with `rowadd_l` [L, B] added to
 // layer l's dH before its mask when given: Hedge), dL/dbi into gbi_out when given, every layer's dW | db in one launch,
 // then the fixed-order reduction into `grads` (+ optional SGD, + the mean of w.loss_b into loss_out when given)
 // skip_dgrad: k_mlp_chain has already produced every dH_l and gbi; only the weight gradients and their reduction remain
 static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const float *bi, int32_t ld_bi, int32_t B,
                              const float *rowadd_l, float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply,
-                             float *loss_out, float inv_b, hipStream_t st, bool skip_dgrad = false) {
+                             float *loss_out, float inv_b, hipStream_t st, bool skip_dgrad = false, MlpReduceArgs *deferred = nullptr) {
   const int L = mlp->n_layers, H = mlp->hidden, k = mlp->k;
   const size_t act = align_up((size_t)B * H * 4, 256) / 4;
   const float *Wl[MLP_BIG_MAX_L];
@@ -235,7 +249,6 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
     hipLaunchKernelGGL(k_mlp_wgrad, dim3(8 * ((zs + 7) / 8) * per), dim3(256), g_lds_bytes(G_BK_WGRAD), st, wb);
   }
   MlpReduceArgs a;
-  long long biggest = 0;
   for (int l = 0; l < MLP_BIG_MAX_L; ++l) {
     const int in = l == 0 ? k : H;
     a.parts[l] = l < L ? w.parts[l] : nullptr;
@@ -244,7 +257,6 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
     a.ldp[l] = l < L ? w.ldp[l] : 0;
     a.grad_off[l] = l < L ? off[l] : 0;
     a.n_split[l] = splits[l];
-    if (l < L && (long long)H * (in + 1) > biggest) biggest = (long long)H * (in + 1);
   }
   a.grads = grads;
   a.params = mlp->params;
@@ -254,8 +266,11 @@ static void mlp_big_backward(const fmx_mlp_t *mlp, const MlpBigWs &w, const floa
   a.loss_out = loss_out;
   a.B = B;
   a.inv_b = inv_b;
-  const int bx = (int)((biggest + 255) / 256);
-  hipLaunchKernelGGL(k_mlp_reduce, dim3(bx > 256 ? 256 : bx, L), dim3(256), 0, st, a);
+  if (deferred) {  // the caller carries the reduction's blocks in another launch (or calls mlp_launch_reduce)
+    *deferred = a;
+    return;
+  }
+  mlp_launch_reduce(a, st);
 }
 
 static int mlp_big_check(const fmx_mlp_t *mlp, int32_t B, const void *workspace, const char *who) {
@@ -269,11 +284,18 @@ static int mlp_big_check(const fmx_mlp_t *mlp, int32_t B, const void *workspace,
 int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, int32_t ld_bi, const float *base,
                     const float *y, int32_t B, float inv_b, void *workspace, float *logit_out, float *dz_out,
                     float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply, float *loss_out, fmx_stream_t stream) {
+  return mlp_section_deferred_reduce(mlp, loss_kind, bi, ld_bi, base, y, B, inv_b, workspace, logit_out, dz_out, gbi_out, ld_gbi, grads, lr_apply,
+                                     loss_out, static_cast<hipStream_t>(stream), nullptr);
+}
+
+extern "C++" int fmxd::mlp_section_deferred_reduce(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, int32_t ld_bi, const float *base,
+                                                   const float *y, int32_t B, float inv_b, void *workspace, float *logit_out, float *dz_out,
+                                                   float *gbi_out, int32_t ld_gbi, float *grads, float lr_apply, float *loss_out, hipStream_t st,
+                                                   MlpReduceArgs *deferred) {
   if (int rc = mlp_big_check(mlp, B, workspace, "fmx_mlp_section")) return rc;
   if (!bi || !base || !y || !dz_out || !gbi_out || !grads) return fail(FMX_ERR_ARG, "fmx_mlp_section: null argument");
   if (ld_bi < mlp->k || ld_gbi < mlp->k) return fail(FMX_ERR_SHAPE, "fmx_mlp_section: ld_bi / ld_gbi smaller than k");
   if (loss_kind != FMX_LOSS_BCE_LOGITS && loss_kind != FMX_LOSS_BCE_SIGMOID) return fail(FMX_ERR_ARG, "fmx_mlp_section needs a loss");
-  hipStream_t st = static_cast<hipStream_t>(stream);
   const MlpBigWs w = mlp_big_carve(mlp, B, workspace);
   const int L = mlp->n_layers, H = mlp->hidden;
   const size_t act = align_up((size_t)B * H * 4, 256) / 4;
@@ -308,7 +330,7 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     c.inv_b = inv_b;
     c.stamps = tune().mlp_chain == 2 ? reinterpret_cast<unsigned long long *>(w.loss_lb) : nullptr;  // debug: tools/mlp_chain_stamps.py
     hipLaunchKernelGGL(k_mlp_chain, dim3((B + CH_R - 1) / CH_R), dim3(256), chain_lds_bytes(H), st, c);
-    mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st, true);
+    mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st, true, deferred);
     return check_launch("fmx_mlp_section (k_mlp_chain)");
   }
   mlp_big_forward(mlp, w, bi, ld_bi, B, st);
@@ -328,7 +350,7 @@ int fmx_mlp_section(const fmx_mlp_t *mlp, int32_t loss_kind, const float *bi, in
     a.inv_b = inv_b;
     hipLaunchKernelGGL(k_mlp_loss, dim3((B + 3) / 4), dim3(256), 0, st, a);
   }
-  mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st);
+  mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st, false, deferred);
   return check_launch("fmx_mlp_section");
 }
 
