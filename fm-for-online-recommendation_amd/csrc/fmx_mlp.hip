@@ -329,6 +329,14 @@ extern "C++" int fmxd::mlp_section_deferred_reduce(const fmx_mlp_t *mlp, int32_t
     c.loss_kind = loss_kind;
     c.inv_b = inv_b;
     c.stamps = tune().mlp_chain == 2 ? reinterpret_cast<unsigned long long *>(w.loss_lb) : nullptr;  // debug: tools/mlp_chain_stamps.py
+#ifdef FMX_MLP_EXPERIMENTS  // diagnostic build only (tools/corun_experiment.py): FMX_EXP_ONLY_WGRAD=1 launches the gradient kernel alone
+    static int only_wgrad = getenv("FMX_EXP_ONLY_WGRAD") ? atoi(getenv("FMX_EXP_ONLY_WGRAD")) : 0;
+    if (only_wgrad) {
+      MlpReduceArgs unused;
+      mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st, true, &unused);
+      return check_launch("fmx_mlp_section (gradient kernel only)");
+    }
+#endif
     hipLaunchKernelGGL(k_mlp_chain, dim3((B + CH_R - 1) / CH_R), dim3(256), chain_lds_bytes(H), st, c);
     mlp_big_backward(mlp, w, bi, ld_bi, B, nullptr, gbi_out, ld_gbi, grads, lr_apply, loss_out, inv_b, st, true, deferred);
     return check_launch("fmx_mlp_section (k_mlp_chain)");

@@ -1,5 +1,7 @@
-"""Timing experiment: k_mlp_wgrad_stream (FMX_EXP_ONLY_WGRAD=1 build: the section launches only it) beside k_fm_update on two
-unordered streams against the two in sequence on one stream."""
+"""Timing experiment: k_mlp_wgrad_stream beside k_fm_update on two unordered streams against the two in sequence on one stream.
+Needs a DIAGNOSTIC build of the library in which fmx_mlp_section can launch the gradient kernel alone:
+    cd fm-for-online-recommendation_amd/csrc && make FLAGS_EXTRA=-DFMX_MLP_EXPERIMENTS   (or add the define to FLAGS by hand)
+with the product library the "wgrad" lines time the whole section."""
 import os, sys, ctypes as C, time
 os.environ["FMX_EXP_ONLY_WGRAD"] = "1"
 sys.path.insert(0, "/root/repo/fm-for-online-recommendation_amd"); sys.path.insert(0, "/root/repo")
